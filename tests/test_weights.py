@@ -1,0 +1,69 @@
+"""Weight formats either side of the path (viettts_amd/hifigan/weights.py)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from viettts_amd.hifigan.config import TINY, V1, HifiganConfig
+from viettts_amd.hifigan.synth import synthetic_params
+from viettts_amd.hifigan.weights import (check_params, conv_specs, haiku_to_state_dict, load_haiku_pickle, num_parameters,
+                                          save_haiku_pickle, state_dict_to_haiku, torch_weight_to_haiku)
+
+
+def test_inventory_matches_reference():
+    specs = conv_specs(V1)
+    assert len(specs) == 78  # 1 + 4 + 72 + 1
+    assert num_parameters(V1) == 13926017
+    keys = [s.key for s in specs]
+    assert keys[0] == "generator/~/conv1_d" and keys[-1] == "generator/~/conv1_d_1"
+    assert "generator/~/res_block1_11/~/convs2_2" in keys
+    by = {s.key: s for s in specs}
+    assert by["generator/~/ups_0"].w_shape == (16, 256, 512)
+    assert by["generator/~/res_block1_4/~/convs1_2"].w_shape == (7, 128, 128)
+    assert by["generator/~/res_block1_4/~/convs1_2"].dilation == 5
+    assert by["generator/~/res_block1_4/~/convs2_2"].dilation == 1
+    assert by["generator/~/conv1_d_1"].w_shape == (7, 32, 1)
+
+
+def test_layout_map_is_the_converters():
+    """convert_torch_model_to_haiku.py:53-56: rot90(axes=(0,2)) for ups, swapaxes(0,2) for convs."""
+    rng = np.random.default_rng(1)
+    by = {s.key: s for s in conv_specs(V1)}
+    up = by["generator/~/ups_2"]
+    w = rng.standard_normal(up.torch_w_shape).astype(np.float32)
+    assert np.array_equal(torch_weight_to_haiku(up, w), np.rot90(w, k=1, axes=(0, 2)))
+    cv = by["generator/~/res_block1_9/~/convs1_1"]
+    w = rng.standard_normal(cv.torch_w_shape).astype(np.float32)
+    assert np.array_equal(torch_weight_to_haiku(cv, w), np.swapaxes(w, 0, 2))
+
+
+def test_roundtrip_and_pickle(tmp_path):
+    p = synthetic_params(TINY, 7)
+    check_params(TINY, p)
+    sd = haiku_to_state_dict(TINY, p)
+    q = state_dict_to_haiku(TINY, sd)
+    for k in p:
+        assert np.array_equal(p[k]["w"], q[k]["w"]) and np.array_equal(p[k]["b"], q[k]["b"])
+    # non-contiguous views, as the reference converter pickles them
+    views = {k: {"w": np.swapaxes(np.swapaxes(m["w"], 0, 2).copy(), 0, 2), "b": m["b"]} for k, m in p.items()}
+    with open(tmp_path / "hk_hifi.pickle", "wb") as f:
+        pickle.dump(views, f)
+    r = load_haiku_pickle(tmp_path / "hk_hifi.pickle")
+    for k in p:
+        assert r[k]["w"].flags["C_CONTIGUOUS"] and np.array_equal(r[k]["w"], p[k]["w"])
+    save_haiku_pickle(tmp_path / "x.pickle", p)
+    assert set(load_haiku_pickle(tmp_path / "x.pickle")) == set(p)
+
+
+def test_check_params_errors():
+    p = synthetic_params(TINY, 7)
+    bad = dict(p)
+    del bad["generator/~/ups_1"]
+    with pytest.raises(ValueError):
+        check_params(TINY, bad)
+    bad = {k: dict(v) for k, v in p.items()}
+    bad["generator/~/ups_1"]["w"] = bad["generator/~/ups_1"]["w"][:-1]
+    with pytest.raises(ValueError):
+        check_params(TINY, bad)
+    with pytest.raises(ValueError):
+        HifiganConfig.from_dict({"resblock": "2"})
