@@ -1,0 +1,208 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the mel->waveform hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the HiFi-GAN V1 generator over one batch of synthetic mels already resident
+in HBM: per GPU ``--batch`` utterances x ``--frames`` mel frames (defaults 64 x 1024 = BASELINE.json
+configs[2], the shape the samples/sec metric is quoted on).  Weak scaling: every rank runs the same
+per-GPU batch on its own shard; the packed weights are broadcast once from rank 0 (RCCL) and there is
+no data-path collective.  Rank 0 prints ONE JSON line with:
+  value        whole-job audio samples/sec (all N GPUs), inputs resident in HBM
+  rtf_b1       latency / RTF of a single 512-frame utterance (BASELINE configs[1]), rank 0
+  roofline     dominant ResBlock-conv kernel: algorithmic FLOPs / HIP-event time, vs the MFMA peak
+  cpu_baseline the oracle (numpy restatement of the reference) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from viettts_amd import dist as vdist  # noqa: E402
+from viettts_amd.hifigan.config import V1  # noqa: E402
+from viettts_amd.hifigan.generator import Generator  # noqa: E402
+from viettts_amd.hifigan.synth import synthetic_mel, synthetic_params  # noqa: E402
+
+FLOP_PER_SAMPLE = 2398848  # 2 x MAC of all convolutions per output sample
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def cpu_baseline(reps: int = 3, T: int = 512):
+    """The oracle (CPU restatement of the reference generator, fp32, BLAS-threaded) on the host
+    cores.  Bounded sample: `reps` single utterances of T frames.  Baseline only."""
+    from oracle.hifigan_oracle import generator_forward
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    params = synthetic_params(V1, 4321, "scaled")
+    mel = synthetic_mel(1, T, 1234)
+    generator_forward(params, mel[:, :32], V1, np.float32)  # warm-up (BLAS threads, page-in)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        generator_forward(params, mel, V1, np.float32)
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {
+        "value": 256 * T / med,
+        "unit": "samples/s",
+        "cores": int(cores),
+        "kind": "port",
+        "sample": f"oracle/hifigan_oracle.py fp32 (numpy+BLAS restatement of the reference generator), B=1 x T={T} frames, median of {reps}",
+        "ms": med * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=1024, help="mel frames per utterance")
+    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--microbatch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rtf", action="store_true")
+    args = ap.parse_args()
+
+    info = vdist.init_process_group()
+    if info.world != args.gpus:
+        if info.rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}; using WORLD_SIZE", file=sys.stderr)
+    n_gpus = info.world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(info.local_rank)
+    dev = torch.device("cuda", info.local_rank)
+
+    gen = Generator(V1, device=dev, dtype=args.dtype)
+    vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info)
+    if args.microbatch:
+        gen.set_option("microbatch", args.microbatch)
+
+    B, T = args.batch, args.frames
+    # per-rank shard of the global batch: distinct seeded mels, resident in HBM before timing
+    mel = torch.from_numpy(synthetic_mel(B, T, 1234 + info.rank)).to(dev)
+    out = torch.empty((B, 256 * T), dtype=torch.float32, device=dev)
+
+    def barrier():
+        if n_gpus > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        gen(mel, out)
+    torch.cuda.synchronize()
+    gen.set_option("profile", 1)
+    gen.profile_read(reset=True)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gen(mel, out)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = gen.profile_read(reset=True)
+    gen.set_option("profile", 0)
+
+    if n_gpus > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    assert bool(torch.isfinite(out[0, :4096]).all()), "non-finite output"
+
+    if info.rank == 0:
+        samples_per_step = n_gpus * B * 256 * T
+        value = samples_per_step * args.steps / elapsed
+        res = {
+            "metric": "audio samples/sec whole-node, HiFi-GAN V1 mel2wave",
+            "value": value,
+            "unit": "samples/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic (seeded random weights of the V1 architecture, seeded log-mel-like inputs)",
+            "config": {
+                "workload": f"HiFi-GAN V1 generator, {B} utterances x {T} mel frames per GPU per step (BASELINE configs[2] shape), {args.dtype}",
+                "batch_per_gpu": B,
+                "frames": T,
+                "samples_per_step": samples_per_step,
+                "parallelism": f"dp{n_gpus} utterance-sharded, weights broadcast once, no data-path collective",
+                "microbatch": gen.get_option("microbatch"),
+            },
+            "tflops_whole_job": value * FLOP_PER_SAMPLE / 1e12,
+            "frac_of_mfma_peak_whole_forward": value * FLOP_PER_SAMPLE / 1e12 / (PEAK_TFLOPS[args.dtype] * n_gpus),
+        }
+        # ---- roofline of the dominant kernel, HIP events on the launch stream, timed region only ----
+        if prof["launches"] > 0 and prof["ms"] > 0:
+            ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            res["roofline"] = {
+                "bound": "mfma",
+                "achieved": ach,
+                "peak": PEAK_TFLOPS[args.dtype],
+                "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[args.dtype],
+                "traffic": None,
+                "kernel": prof["kernel"],
+                "launches": prof["launches"],
+                "avg_launch_ms": prof["ms"] / prof["launches"],
+                "flops_per_launch": prof["flops"] / prof["launches"],
+            }
+        else:
+            res["roofline"] = None
+
+        # ---- RTF at batch 1 (BASELINE configs[1]: B=1, T=512) ----
+        if not args.no_rtf:
+            m1 = torch.from_numpy(synthetic_mel(1, 512, 1234)).to(dev)
+            o1 = torch.empty((1, 256 * 512), dtype=torch.float32, device=dev)
+            for _ in range(3):
+                gen(m1, o1)
+            torch.cuda.synchronize()
+            lat = []
+            for _ in range(20):
+                t1 = time.perf_counter()
+                gen(m1, o1)
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t1)
+            med = statistics.median(lat)
+            res["rtf_b1"] = {
+                "workload": "B=1, T=512 frames (131072 samples)",
+                "latency_ms": med * 1e3,
+                "rtf_16000": med / (131072 / 16000.0),
+                "rtf_22050": med / (131072 / 22050.0),
+                "samples_per_s": 131072 / med,
+            }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+
+    barrier()
+    gen.close()
+    if n_gpus > 1 and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

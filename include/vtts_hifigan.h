@@ -1,0 +1,162 @@
+/*
+ * vtts_hifigan.h — C ABI of the MI355X-native mel->waveform hot path of NTT123/vietTTS.
+ *
+ * This is the drop-in boundary: the entry points a maintainer of the reference would bind
+ * (ctypes stub in INTEGRATION.md) to replace the body of
+ *     vietTTS/hifigan/mel2wave.py:20-41   mel2wave(mel)
+ * i.e. "load hk_hifi.pickle, build Generator(h), apply it to mel".  Plain pointers and sizes
+ * only; no torch / pybind types.  Every function returns 0 on success or a negative
+ * vtts_status; the message for the last failure on the calling thread is
+ * vtts_last_error().  Nothing throws across this boundary.
+ *
+ * Threading: a handle is not thread-safe; use one handle per GPU / stream.  forward() is
+ * asynchronous on the given hipStream_t.  Device memory (packed weights, workspace, mel, wav)
+ * is owned by the CALLER (PyTorch-ROCm tensors in the shipped host layer); the handle owns only
+ * small host-side tables.
+ */
+#ifndef VTTS_HIFIGAN_H
+#define VTTS_HIFIGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VTTS_ABI_VERSION 1
+
+typedef enum vtts_status {
+    VTTS_OK = 0,
+    VTTS_ERR_INVALID = -1,     /* bad argument / unsupported configuration            */
+    VTTS_ERR_STATE = -2,       /* call order violated (e.g. forward before bind)       */
+    VTTS_ERR_MISSING = -3,     /* a parameter array was never supplied                 */
+    VTTS_ERR_HIP = -4,         /* a HIP runtime call failed (message has the hipError) */
+    VTTS_ERR_NOMEM = -5,       /* workspace too small / host allocation failed         */
+    VTTS_ERR_SHAPE = -6        /* array shape does not match the architecture          */
+} vtts_status;
+
+typedef enum vtts_dtype {
+    VTTS_F32 = 0,  /* fp32 operands, fp32 accumulate: v_mfma_f32_32x32x2_f32 (exact fmaf chain) */
+    VTTS_BF16 = 1  /* bf16 operands, fp32 accumulate: v_mfma_f32_32x32x16_bf16                  */
+} vtts_dtype;
+
+#define VTTS_MAX_UPSAMPLES 8
+#define VTTS_MAX_KERNELS 4
+
+/*
+ * The architecture-defining fields Generator.__init__ reads from the JSON config
+ * (vietTTS/hifigan/model.py:81-106; assets/hifigan/config.json:2,11-15,19).
+ * Only resblock == "1" (ResBlock1, model.py:13-51) exists on this path.
+ */
+typedef struct vtts_hifigan_cfg {
+    int32_t num_mels;                                        /* 80  */
+    int32_t upsample_initial_channel;                        /* 512 */
+    int32_t num_upsamples;                                   /* 4   */
+    int32_t upsample_rates[VTTS_MAX_UPSAMPLES];              /* 8,8,2,2     */
+    int32_t upsample_kernel_sizes[VTTS_MAX_UPSAMPLES];       /* 16,16,4,4   */
+    int32_t num_kernels;                                     /* 3   */
+    int32_t resblock_kernel_sizes[VTTS_MAX_KERNELS];         /* 3,7,11      */
+    int32_t resblock_dilation_sizes[VTTS_MAX_KERNELS][3];    /* 1,3,5 each  */
+} vtts_hifigan_cfg;
+
+typedef struct vtts_hifigan vtts_hifigan; /* opaque */
+typedef void* vtts_stream;                /* a hipStream_t (0 = default stream) */
+
+/* ABI version of the loaded library (== VTTS_ABI_VERSION of the header it was built from). */
+int vtts_abi_version(void);
+
+/* Message describing the last error raised on this thread ("" if none). */
+const char* vtts_last_error(void);
+
+/*
+ * Build the host-side plan for one generator on HIP device `device`.
+ * Replaces: Generator(h) construction, vietTTS/hifigan/model.py:78-107 (via mel2wave.py:28-31).
+ */
+int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dtype, vtts_hifigan** out);
+void vtts_hifigan_destroy(vtts_hifigan* h);
+
+/*
+ * Supply one parameter array in the layout of hk_hifi.pickle (mel2wave.py:35-36; produced by
+ * convert_torch_model_to_haiku.py:50-58): key e.g. "generator/~/res_block1_4/~/convs1_2",
+ * which = "w" ([K,Cin,Cout] for convs, [K,Cout,Cin] for ups_*) or "b" ([Cout]).  `host` is
+ * fp32 host memory, copied before return.
+ */
+int vtts_hifigan_set_param(vtts_hifigan* h, const char* key, const char* which, const float* host,
+                           const int64_t* shape, int ndim);
+
+/* Number of parameter arrays the architecture needs (156 for V1) and the i-th one's key. */
+int vtts_hifigan_num_params(const vtts_hifigan* h, int* n);
+int vtts_hifigan_param_info(const vtts_hifigan* h, int i, const char** key, const char** which,
+                            int64_t shape[3], int* ndim);
+
+/*
+ * Size of the packed (kernel-private layout) weight blob, and the two ways to get one bound:
+ *  - pack():  re-lay-out every array supplied via set_param into `dev_blob` (device memory of
+ *             packed_bytes() bytes, 256-B aligned, caller-owned) on `stream`, and bind it;
+ *  - bind_packed(): bind a blob that already holds packed weights — e.g. one received by an
+ *             RCCL broadcast from the rank that called pack().  The packing depends only on
+ *             (cfg, dtype, ABI version), so blobs are interchangeable between ranks.
+ * Replaces: pickle.load of the parameters on every call, mel2wave.py:35-36.
+ */
+int vtts_hifigan_packed_bytes(const vtts_hifigan* h, size_t* bytes);
+int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_bytes, vtts_stream stream);
+int vtts_hifigan_bind_packed(vtts_hifigan* h, void* dev_blob, size_t blob_bytes);
+
+/* Scratch bytes forward() needs for a batch of B utterances of T mel frames. */
+int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, size_t* bytes);
+
+/*
+ * The hot path.  Replaces forward.apply(params, aux, rng, mel) + squeeze,
+ * vietTTS/hifigan/mel2wave.py:37-39 == Generator.__call__, model.py:109-125.
+ *   mel_dev : [B, T, num_mels] fp32, NWC (the reference's layout), device memory
+ *   wav_dev : [B, hop*T] fp32 in (-1,1), device memory (hop = prod(upsample_rates) = 256)
+ * Asynchronous on `stream`; the caller synchronises before reading wav_dev.
+ */
+int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev,
+                         void* workspace, size_t workspace_bytes, vtts_stream stream);
+
+/*
+ * forward() that also copies one intermediate out, for parity tests.  `tap` names follow the
+ * oracle: "conv_pre", "ups_<i>", "mrf_<i>" (each [B, C, L] fp32, channel-major) and
+ * "pre_tanh" ([B, hop*T]).  tap_dev must hold vtts_hifigan_tap_elems() floats.
+ */
+int vtts_hifigan_tap_elems(const vtts_hifigan* h, const char* tap, int B, int T, size_t* elems);
+int vtts_hifigan_forward_tap(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev,
+                             void* workspace, size_t workspace_bytes, vtts_stream stream,
+                             const char* tap, float* tap_dev);
+
+/*
+ * Run ONE convolution module of the generator on caller-provided activations (per-layer known
+ * answer tests).  x_dev/y_dev/res_dev are [B, C, L] fp32 channel-major (the engine's internal
+ * layout); for "generator/~/conv1_d" x_dev is [B, L, num_mels] as at the boundary.
+ *   slope_in : LeakyReLU slope applied to the input on load (1.0 = none)
+ *   res_dev  : optional residual added to the output (may alias y_dev), or NULL
+ * The output length is L for convolutions and stride*L for ups_*.
+ */
+int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev, int B, int L,
+                            float slope_in, const float* res_dev, float* y_dev, vtts_stream stream);
+
+/*
+ * Engine options (tests / benchmarks):
+ *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
+ *   "microbatch" utterances processed per pass through the network (0 = auto)
+ */
+int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value);
+int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, int64_t* value);
+
+/*
+ * Kernel-level timing hook for bench.py: when enabled ("profile" option = 1), forward()
+ * brackets the dominant kernel class (ResBlock convolutions) with hipEvents on `stream`;
+ * after a stream sync, this returns the accumulated milliseconds and launch count since the
+ * last reset, and the algorithmic FLOPs those launches performed.
+ */
+int vtts_hifigan_profile_read(vtts_hifigan* h, double* resblock_ms, int64_t* launches,
+                              double* resblock_flops, int reset);
+/* Name prefix of the kernel those events bracket (as rocprofv3 --kernel-trace prints it). */
+const char* vtts_hifigan_profile_kernel(const vtts_hifigan* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VTTS_HIFIGAN_H */

@@ -1,0 +1,113 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/vtts_hifigan.h declares;
+host-side planning (no compute) behaves as the header says."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+from viettts_amd import _lib
+from viettts_amd.hifigan.config import TINY, V1
+from viettts_amd.hifigan.weights import conv_specs
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from viettts_amd.csrc.build import build
+
+    build()  # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_symbols_all_exported(lib):
+    header = (REPO / "include" / "vtts_hifigan.h").read_text()
+    declared = set(re.findall(r"\b(vtts_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vtts_abi_version() == _lib.ABI_VERSION
+
+
+def _create(lib, cfg, dtype=_lib.VTTS_F32):
+    h = C.c_void_p(0)
+    cs = _lib.make_cfg(cfg)
+    _lib.check(lib, lib.vtts_hifigan_create(C.byref(cs), 0, dtype, C.byref(h)))
+    return h
+
+
+def test_plan_matches_python_inventory(lib):
+    h = _create(lib, V1)
+    n = C.c_int(0)
+    _lib.check(lib, lib.vtts_hifigan_num_params(h, C.byref(n)))
+    assert n.value == 156
+    specs = conv_specs(V1)
+    for i in range(n.value):
+        key, which = C.c_char_p(), C.c_char_p()
+        shape = (C.c_int64 * 3)()
+        nd = C.c_int(0)
+        _lib.check(lib, lib.vtts_hifigan_param_info(h, i, C.byref(key), C.byref(which), shape, C.byref(nd)))
+        s = specs[i // 2]
+        assert key.value.decode() == s.key
+        if i % 2 == 0:
+            assert which.value == b"w" and tuple(shape[:3]) == tuple(s.w_shape)
+        else:
+            assert which.value == b"b" and shape[0] == s.cout and nd.value == 1
+    nb = C.c_size_t(0)
+    _lib.check(lib, lib.vtts_hifigan_packed_bytes(h, C.byref(nb)))
+    assert nb.value >= 13926017 * 4
+    ws = C.c_size_t(0)
+    _lib.check(lib, lib.vtts_hifigan_set_option(h, b"microbatch", 1))
+    _lib.check(lib, lib.vtts_hifigan_workspace_bytes(h, 64, 1024, C.byref(ws)))
+    assert ws.value == 4 * 8192 * 1024 * 4  # four [C][L] buffers of the widest stage, one utterance
+    hop = C.c_int64(0)
+    _lib.check(lib, lib.vtts_hifigan_get_option(h, b"hop", C.byref(hop)))
+    assert hop.value == 256
+    lib.vtts_hifigan_destroy(h)
+
+
+def test_error_paths(lib):
+    h = _create(lib, TINY)
+    # forward before weights are bound
+    rc = lib.vtts_hifigan_forward(h, C.c_void_p(256), 1, 4, C.c_void_p(256), C.c_void_p(256), 1 << 30, None)
+    assert rc == -2 and b"before pack" in lib.vtts_last_error()
+    # unknown module / wrong shape
+    buf = (C.c_float * 8)()
+    shp = (C.c_int64 * 3)(1, 2, 3)
+    assert lib.vtts_hifigan_set_param(h, b"generator/~/nope", b"w", buf, shp, 3) == -1
+    assert lib.vtts_hifigan_set_param(h, b"generator/~/ups_0", b"w", buf, shp, 3) == -6
+    assert lib.vtts_hifigan_set_param(h, b"generator/~/ups_0", b"q", buf, shp, 3) == -1
+    # pack with parameters missing
+    assert lib.vtts_hifigan_pack(h, C.c_void_p(256), 1 << 30, None) == -3
+    assert b"never set" in lib.vtts_last_error()
+    assert lib.vtts_hifigan_set_option(h, b"bogus", 1) == -1
+    n = C.c_size_t(0)
+    assert lib.vtts_hifigan_workspace_bytes(h, 0, 4, C.byref(n)) == -1
+    lib.vtts_hifigan_destroy(h)
+    # unsupported configurations are rejected at create()
+    bad = _lib.make_cfg(V1)
+    bad.resblock_kernel_sizes[0] = 4
+    hh = C.c_void_p(0)
+    assert lib.vtts_hifigan_create(C.byref(bad), 0, _lib.VTTS_F32, C.byref(hh)) == -1
+    with pytest.raises(_lib.VttsError):
+        _lib.check(lib, lib.vtts_hifigan_create(C.byref(bad), 0, _lib.VTTS_F32, C.byref(hh)))
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Generator refuses CPU devices; mel2wave refuses to run without a GPU; nothing under
+    viettts_amd/ imports the oracle."""
+    import torch
+
+    from viettts_amd.hifigan.generator import Generator
+
+    with pytest.raises(ValueError):
+        Generator(V1, device="cpu")
+    if not torch.cuda.is_available():
+        from viettts_amd.hifigan import mel2wave as m2w
+
+        with pytest.raises((RuntimeError, FileNotFoundError)):
+            m2w.mel2wave([[[0.0] * 80]])
+    for p in (REPO / "viettts_amd").rglob("*.py"):
+        src = p.read_text()
+        assert "import oracle" not in src and "from oracle" not in src, p

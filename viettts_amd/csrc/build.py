@@ -1,0 +1,87 @@
+"""Build libvtts_hifigan.so (gfx950) in-tree with hipcc.
+
+    python -m viettts_amd.csrc.build [--force] [--verbose]
+
+The shared object lands in viettts_amd/lib/ so that it travels with the source tree to the GPU
+box (it is git-ignored, not gpurun-ignored).  hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+ROOT = CSRC.parents[1]
+LIBDIR = CSRC.parent / "lib"
+OBJDIR = CSRC / "build"
+SOURCES = ["engine.hip", "kernels_generic.hip", "kernels_f32_mfma.hip"]
+HEADERS = ["vtts_internal.h", "device_common.h", str(ROOT / "include" / "vtts_hifigan.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+LIBNAME = "libvtts_hifigan.so"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS + [__file__]:
+        p = Path(name) if os.path.isabs(str(name)) else CSRC / name
+        h.update(p.read_bytes())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def lib_path() -> Path:
+    return LIBDIR / LIBNAME
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    LIBDIR.mkdir(parents=True, exist_ok=True)
+    OBJDIR.mkdir(parents=True, exist_ok=True)
+    stamp = LIBDIR / (LIBNAME + ".sha256")
+    dig = _digest()
+    out = lib_path()
+    if not force and out.exists() and stamp.exists() and stamp.read_text().strip() == dig:
+        return out
+    hipcc = _hipcc()
+
+    def compile_one(src: str) -> Path:
+        obj = OBJDIR / (Path(src).stem + ".o")
+        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *map(str, objs)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    stamp.write_text(dig + "\n")
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))

@@ -1,0 +1,600 @@
+// Host-side engine behind the C ABI of include/vtts_hifigan.h.
+//
+// Holds the execution plan of the HiFi-GAN generator (vietTTS/hifigan/model.py:78-125): the 78
+// convolution modules in execution order, where each one's weights live in the packed device blob,
+// and the schedule that fuses LeakyReLU / bias / residual / MRF mean / tanh into the convolution
+// kernels.  All device memory is caller-owned (blob, workspace, mel, wav).
+#include "../../include/vtts_hifigan.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vtts_internal.h"
+
+using namespace vtts;
+
+#define VTTS_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(VTTS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+enum Kind { KIND_CONV = 0, KIND_CONVT = 1 };
+
+struct Layer {
+    std::string key;
+    int kind = KIND_CONV;
+    int cin = 0, cout = 0, k = 0, dil = 1, stride = 1;
+    int pad = 0;    // conv: symmetric pad, get_padding (model.py:8-10)
+    int pad_a = 0;  // convT: left pad of the zero-stuffed input (lax "SAME")
+    // host copies (Haiku layout)
+    std::vector<float> w, b;
+    bool have_w = false, have_b = false;
+    // packed blob offsets in bytes
+    size_t off_w = 0, off_b = 0, off_wp = 0;
+    bool has_wp = false;
+    size_t wp_floats = 0;
+};
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct vtts_hifigan {
+    vtts_hifigan_cfg cfg;
+    int device = 0;
+    int dtype = VTTS_F32;
+    int hop = 1;
+    std::vector<Layer> layers;       // execution order
+    int idx_pre = -1, idx_post = -1;
+    std::vector<int> idx_ups;        // per stage
+    std::vector<int> idx_res;        // [stage][kernel][z][convs1|convs2] flattened: base index of each resblock
+    size_t blob_bytes = 0;
+    char* blob = nullptr;            // bound device blob (caller-owned)
+    // options
+    int64_t opt_kernels = 0;         // 0 auto, 1 generic only
+    int64_t opt_microbatch = 0;      // 0 auto
+    int64_t opt_profile = 0;
+    // profiling of the dominant kernel class
+    int prof_C = 0, prof_K = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    size_t prof_used = 0;
+    double prof_flops = 0.0;
+    std::string prof_name;
+};
+
+namespace {
+
+int conv_same_pad_a(int k, int s) {
+    // lax.conv_transpose padding="SAME": pad_len = k + s - 2; pad_a = k-1 if s > k-1 else ceil(pad_len/2)
+    const int pad_len = k + s - 2;
+    return (s > k - 1) ? (k - 1) : (pad_len + 1) / 2;
+}
+
+int build_layers(vtts_hifigan* h) {
+    const vtts_hifigan_cfg& c = h->cfg;
+    auto add = [&](const std::string& key, int kind, int cin, int cout, int k, int dil, int stride) {
+        Layer l;
+        l.key = key;
+        l.kind = kind;
+        l.cin = cin;
+        l.cout = cout;
+        l.k = k;
+        l.dil = dil;
+        l.stride = stride;
+        if (kind == KIND_CONV) l.pad = (k * dil - dil) / 2;
+        else l.pad_a = conv_same_pad_a(k, stride);
+        h->layers.push_back(l);
+        return (int)h->layers.size() - 1;
+    };
+    const int c0 = c.upsample_initial_channel;
+    h->idx_pre = add("generator/~/conv1_d", KIND_CONV, c.num_mels, c0, 7, 1, 1);
+    int n = 0;
+    h->hop = 1;
+    for (int i = 0; i < c.num_upsamples; ++i) {
+        const int cin = c0 >> i, cout = c0 >> (i + 1);
+        h->idx_ups.push_back(add("generator/~/ups_" + std::to_string(i), KIND_CONVT, cin, cout,
+                                 c.upsample_kernel_sizes[i], 1, c.upsample_rates[i]));
+        h->hop *= c.upsample_rates[i];
+        for (int j = 0; j < c.num_kernels; ++j) {
+            const std::string base = "generator/~/res_block1_" + std::to_string(n) + "/~/";
+            int first = -1;
+            for (int z = 0; z < 3; ++z) {
+                int i1 = add(base + "convs1_" + std::to_string(z), KIND_CONV, cout, cout, c.resblock_kernel_sizes[j],
+                             c.resblock_dilation_sizes[j][z], 1);
+                int i2 = add(base + "convs2_" + std::to_string(z), KIND_CONV, cout, cout, c.resblock_kernel_sizes[j], 1, 1);
+                (void)i2;
+                if (z == 0) first = i1;
+            }
+            h->idx_res.push_back(first);  // layers first..first+5 = c1_0, c2_0, c1_1, c2_1, c1_2, c2_2
+            ++n;
+        }
+    }
+    h->idx_post = add("generator/~/conv1_d_1", KIND_CONV, c0 >> c.num_upsamples, 1, 7, 1, 1);
+
+    // blob layout: per layer plain weights, bias, optional MFMA-packed weights; 256-B aligned
+    size_t off = 0;
+    double best_flops = -1.0;
+    long len = 1;  // output positions per mel frame
+    for (auto& l : h->layers) {
+        l.off_w = off;
+        off = align_up(off + (size_t)l.k * l.cin * l.cout * sizeof(float), 256);
+        l.off_b = off;
+        off = align_up(off + (size_t)l.cout * sizeof(float), 256);
+        if (l.kind == KIND_CONVT) len *= l.stride;
+        if (h->dtype == VTTS_F32 && l.kind == KIND_CONV && l.cin == l.cout &&
+            conv1d_f32_mfma_supported(l.cin, l.k, l.dil, 4)) {
+            l.has_wp = true;
+            l.wp_floats = conv1d_f32_mfma_packed_floats(l.cin, l.k);
+            l.off_wp = off;
+            off = align_up(off + l.wp_floats * sizeof(float), 256);
+            // dominant kernel class = the (C, K) with the most FLOPs per mel frame
+            double fl = 0.0;
+            long len2 = 1;
+            for (auto& m : h->layers) {
+                if (m.kind == KIND_CONVT) len2 *= m.stride;
+                if (m.kind == KIND_CONV && m.cin == l.cin && m.k == l.k && m.cin == m.cout) fl += 2.0 * len2 * m.cin * m.cout * m.k;
+            }
+            if (fl > best_flops) {
+                best_flops = fl;
+                h->prof_C = l.cin;
+                h->prof_K = l.k;
+            }
+        }
+    }
+    h->blob_bytes = off;
+    if (h->prof_C) h->prof_name = conv1d_f32_mfma_kernel_name(h->prof_C, h->prof_K);
+    return VTTS_OK;
+}
+
+Layer* find_layer(vtts_hifigan* h, const char* key) {
+    for (auto& l : h->layers)
+        if (l.key == key) return &l;
+    return nullptr;
+}
+
+// ---- one convolution launch -------------------------------------------------------------------
+struct Act {  // channel-major activation view
+    const float* p;
+    long sb, sc, st;
+};
+
+int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_in, const float* res, float* y,
+              int acc_mode, float div, int tanh_out, float* pre_act, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x.p;
+    a.x_sb = x.sb;
+    a.x_sc = x.sc;
+    a.x_st = x.st;
+    a.w = reinterpret_cast<const float*>(h->blob + l.off_w);
+    a.wp = l.has_wp ? (h->blob + l.off_wp) : nullptr;
+    a.bias = reinterpret_cast<const float*>(h->blob + l.off_b);
+    a.res = res;
+    a.y = y;
+    a.B = B;
+    a.Cin = l.cin;
+    a.Cout = l.cout;
+    a.K = l.k;
+    a.dil = l.dil;
+    a.pad = l.pad;
+    a.stride = l.stride;
+    a.pad_a = l.pad_a;
+    a.L = L;
+    a.Lout = (l.kind == KIND_CONVT) ? L * l.stride : L;
+    a.slope_in = slope_in;
+    a.acc_mode = acc_mode;
+    a.div = div;
+    a.tanh_out = tanh_out;
+    a.pre_act = pre_act;
+
+    hipError_t e;
+    if (l.kind == KIND_CONVT) {
+        e = launch_convT1d_generic(a, s);
+    } else {
+        const bool mfma = h->opt_kernels == 0 && l.has_wp && x.st == 1 && x.sc == L && (x.sb % 4) == 0 &&
+                          conv1d_f32_mfma_supported(l.cin, l.k, l.dil, L) && !tanh_out;
+        if (mfma) {
+            const bool prof = h->opt_profile && l.cin == h->prof_C && l.k == h->prof_K;
+            if (prof) {
+                if (h->prof_used == h->prof_events.size()) {
+                    hipEvent_t e0, e1;
+                    HIP_TRY(hipEventCreate(&e0));
+                    HIP_TRY(hipEventCreate(&e1));
+                    h->prof_events.emplace_back(e0, e1);
+                }
+                HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+            }
+            e = launch_conv1d_f32_mfma(a, s);
+            if (prof) {
+                HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+                h->prof_used++;
+                h->prof_flops += 2.0 * (double)B * L * l.cin * l.cout * l.k;
+            }
+        } else {
+            e = launch_conv1d_generic(a, s);
+        }
+    }
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "kernel launch for %s failed: %s", l.key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
+size_t max_act_elems(const vtts_hifigan* h, int T) {
+    // largest [C][L] activation per utterance over all stages (8192*T for V1)
+    size_t best = (size_t)h->cfg.upsample_initial_channel * T;
+    long L = T;
+    for (int i = 0; i < h->cfg.num_upsamples; ++i) {
+        L *= h->cfg.upsample_rates[i];
+        size_t e = (size_t)(h->cfg.upsample_initial_channel >> (i + 1)) * L;
+        if (e > best) best = e;
+    }
+    return best;
+}
+
+int pick_microbatch(const vtts_hifigan* h, int B, int T) {
+    if (h->opt_microbatch > 0) return (int)std::min<int64_t>(h->opt_microbatch, B);
+    // enough frames per pass that stage 1 (fewest time tiles) still fills 256 CUs; small enough that
+    // the four activation buffers of a pass stay a few hundred MB (Infinity-Cache friendly)
+    int mb = (4096 + T - 1) / T;
+    if (mb < 1) mb = 1;
+    if (mb > B) mb = B;
+    return mb;
+}
+
+struct Taps {
+    const char* name = nullptr;
+    float* out = nullptr;
+    int Bfull = 0;
+};
+
+int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, size_t ws_bytes, hipStream_t s,
+                 Taps tap) {
+    if (!h->blob) return fail(VTTS_ERR_STATE, "forward() before pack()/bind_packed()");
+    if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive (got B=%d, T=%d)", B, T);
+    size_t need = 0;
+    vtts_hifigan_workspace_bytes(h, B, T, &need);
+    if (ws_bytes < need || !ws) return fail(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(VTTS_ERR_INVALID, "workspace must be 256-B aligned");
+
+    const vtts_hifigan_cfg& c = h->cfg;
+    const int mb = pick_microbatch(h, B, T);
+    const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * sizeof(float), 256);
+    float* bufX = reinterpret_cast<float*>(static_cast<char*>(ws) + 0 * per);   // stage input x (ups output)
+    float* bufT = reinterpret_cast<float*>(static_cast<char*>(ws) + 1 * per);   // xt inside a ResBlock pair
+    float* bufC = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * per);   // running x inside a ResBlock
+    float* bufS = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * per);   // MRF accumulator xs / stage output
+    const int nk = c.num_kernels;
+    const long wav_len = (long)h->hop * T;
+
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = std::min(mb, B - b0);
+        int rc;
+        // conv_pre (model.py:110): mel [nb][T][num_mels] NWC -> S [nb][C0][T]
+        {
+            const Layer& l = h->layers[h->idx_pre];
+            Act x{mel + (long)b0 * T * c.num_mels, (long)T * c.num_mels, 1, c.num_mels};
+            rc = run_layer(h, l, x, nb, T, 1.0f, nullptr, bufS, ACC_STORE, 1.f, 0, nullptr, s);
+            if (rc) return rc;
+            if (tap.name && !strcmp(tap.name, "conv_pre"))
+                HIP_TRY(hipMemcpyAsync(tap.out + (size_t)b0 * l.cout * T, bufS, (size_t)nb * l.cout * T * sizeof(float),
+                                       hipMemcpyDeviceToDevice, s));
+        }
+        long L = T;
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            const Layer& up = h->layers[h->idx_ups[i]];
+            // x = ups_i(leaky_relu(x, 0.1))   (model.py:112-114)
+            Act xin{bufS, (long)up.cin * L, L, 1};
+            rc = run_layer(h, up, xin, nb, (int)L, 0.1f, nullptr, bufX, ACC_STORE, 1.f, 0, nullptr, s);
+            if (rc) return rc;
+            L *= up.stride;
+            const int C = up.cout;
+            const long CL = (long)C * L;
+            if (tap.name && !strncmp(tap.name, "ups_", 4) && atoi(tap.name + 4) == i)
+                HIP_TRY(hipMemcpyAsync(tap.out + (size_t)b0 * CL, bufX, (size_t)nb * CL * sizeof(float), hipMemcpyDeviceToDevice, s));
+            for (int j = 0; j < nk; ++j) {
+                const int base = h->idx_res[i * nk + j];
+                const float* cur = bufX;
+                for (int z = 0; z < 3; ++z) {
+                    const Layer& c1 = h->layers[base + 2 * z];
+                    const Layer& c2 = h->layers[base + 2 * z + 1];
+                    // xt = c1(leaky_relu(x, 0.1))                       (model.py:46-47)
+                    rc = run_layer(h, c1, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, nullptr, bufT, ACC_STORE, 1.f, 0, nullptr, s);
+                    if (rc) return rc;
+                    // x = c2(leaky_relu(xt, 0.1)) + x                  (model.py:48-50)
+                    if (z < 2) {
+                        rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufC, ACC_STORE, 1.f, 0, nullptr, s);
+                        cur = bufC;
+                    } else {
+                        // last pair of the ResBlock: fold the MRF sum / mean into the epilogue (model.py:115-121)
+                        const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
+                        rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufS, mode, (float)nk, 0, nullptr, s);
+                    }
+                    if (rc) return rc;
+                }
+            }
+            if (nk == 1) {
+                // a single-kernel MRF still divides by num_kernels == 1: identity, nothing to do
+            }
+            if (tap.name && !strncmp(tap.name, "mrf_", 4) && atoi(tap.name + 4) == i)
+                HIP_TRY(hipMemcpyAsync(tap.out + (size_t)b0 * CL, bufS, (size_t)nb * CL * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        // tail: tanh(conv_post(leaky_relu(x)))  — slope 0.01, the jax default (model.py:122-124)
+        {
+            const Layer& l = h->layers[h->idx_post];
+            float* pre = (tap.name && !strcmp(tap.name, "pre_tanh")) ? tap.out + (size_t)b0 * wav_len : nullptr;
+            rc = run_layer(h, l, Act{bufS, (long)l.cin * L, L, 1}, nb, (int)L, 0.01f, nullptr, wav + (size_t)b0 * wav_len,
+                           ACC_STORE, 1.f, 1, pre, s);
+            if (rc) return rc;
+        }
+    }
+    return VTTS_OK;
+}
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+VTTS_API int vtts_abi_version(void) { return VTTS_ABI_VERSION; }
+
+VTTS_API const char* vtts_last_error(void) { return g_last_error.c_str(); }
+
+VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dtype, vtts_hifigan** out) {
+    if (!cfg || !out) return fail(VTTS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (dtype != VTTS_F32) return fail(VTTS_ERR_INVALID, "dtype %d not available in this build (only VTTS_F32)", dtype);
+    if (cfg->num_upsamples < 1 || cfg->num_upsamples > VTTS_MAX_UPSAMPLES)
+        return fail(VTTS_ERR_INVALID, "num_upsamples %d out of range", cfg->num_upsamples);
+    if (cfg->num_kernels < 1 || cfg->num_kernels > VTTS_MAX_KERNELS)
+        return fail(VTTS_ERR_INVALID, "num_kernels %d out of range", cfg->num_kernels);
+    if (cfg->num_mels < 1 || cfg->upsample_initial_channel < 1)
+        return fail(VTTS_ERR_INVALID, "num_mels / upsample_initial_channel must be positive");
+    if (cfg->upsample_initial_channel % (1 << cfg->num_upsamples) != 0)
+        return fail(VTTS_ERR_INVALID, "upsample_initial_channel %d not divisible by 2^%d", cfg->upsample_initial_channel,
+                    cfg->num_upsamples);
+    for (int i = 0; i < cfg->num_upsamples; ++i)
+        if (cfg->upsample_rates[i] < 1 || cfg->upsample_kernel_sizes[i] < cfg->upsample_rates[i])
+            return fail(VTTS_ERR_INVALID, "bad upsample stage %d (rate %d, kernel %d)", i, cfg->upsample_rates[i],
+                        cfg->upsample_kernel_sizes[i]);
+    for (int j = 0; j < cfg->num_kernels; ++j) {
+        if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0)
+            return fail(VTTS_ERR_INVALID, "resblock kernel size %d must be odd", cfg->resblock_kernel_sizes[j]);
+        for (int z = 0; z < 3; ++z)
+            if (cfg->resblock_dilation_sizes[j][z] < 1) return fail(VTTS_ERR_INVALID, "dilation must be >= 1");
+    }
+    if (device < 0) return fail(VTTS_ERR_INVALID, "device %d out of range", device);
+    // the device itself is first touched in pack()/bind_packed(): planning needs no GPU
+    auto* h = new (std::nothrow) vtts_hifigan();
+    if (!h) return fail(VTTS_ERR_NOMEM, "host allocation failed");
+    h->cfg = *cfg;
+    h->device = device;
+    h->dtype = dtype;
+    build_layers(h);
+    *out = h;
+    return VTTS_OK;
+}
+
+VTTS_API void vtts_hifigan_destroy(vtts_hifigan* h) {
+    if (!h) return;
+    for (auto& p : h->prof_events) {
+        hipEventDestroy(p.first);
+        hipEventDestroy(p.second);
+    }
+    delete h;
+}
+
+VTTS_API int vtts_hifigan_num_params(const vtts_hifigan* h, int* n) {
+    if (!h || !n) return fail(VTTS_ERR_INVALID, "null argument");
+    *n = 2 * (int)h->layers.size();
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_param_info(const vtts_hifigan* h, int i, const char** key, const char** which, int64_t shape[3],
+                                     int* ndim) {
+    if (!h || !key || !which || !shape || !ndim) return fail(VTTS_ERR_INVALID, "null argument");
+    if (i < 0 || i >= 2 * (int)h->layers.size()) return fail(VTTS_ERR_INVALID, "parameter index %d out of range", i);
+    const Layer& l = h->layers[i / 2];
+    *key = l.key.c_str();
+    if (i % 2 == 0) {
+        *which = "w";
+        *ndim = 3;
+        shape[0] = l.k;
+        shape[1] = (l.kind == KIND_CONV) ? l.cin : l.cout;
+        shape[2] = (l.kind == KIND_CONV) ? l.cout : l.cin;
+    } else {
+        *which = "b";
+        *ndim = 1;
+        shape[0] = l.cout;
+        shape[1] = shape[2] = 0;
+    }
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_set_param(vtts_hifigan* h, const char* key, const char* which, const float* host,
+                                    const int64_t* shape, int ndim) {
+    if (!h || !key || !which || !host || !shape) return fail(VTTS_ERR_INVALID, "null argument");
+    Layer* l = find_layer(h, key);
+    if (!l) return fail(VTTS_ERR_INVALID, "unknown parameter module '%s'", key);
+    if (!strcmp(which, "w")) {
+        const int64_t d1 = (l->kind == KIND_CONV) ? l->cin : l->cout;
+        const int64_t d2 = (l->kind == KIND_CONV) ? l->cout : l->cin;
+        if (ndim != 3 || shape[0] != l->k || shape[1] != d1 || shape[2] != d2)
+            return fail(VTTS_ERR_SHAPE, "%s/w: expected [%d,%lld,%lld]", key, l->k, (long long)d1, (long long)d2);
+        l->w.assign(host, host + (size_t)l->k * l->cin * l->cout);
+        l->have_w = true;
+    } else if (!strcmp(which, "b")) {
+        if (ndim != 1 || shape[0] != l->cout) return fail(VTTS_ERR_SHAPE, "%s/b: expected [%d]", key, l->cout);
+        l->b.assign(host, host + l->cout);
+        l->have_b = true;
+    } else {
+        return fail(VTTS_ERR_INVALID, "parameter name must be \"w\" or \"b\", got \"%s\"", which);
+    }
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_packed_bytes(const vtts_hifigan* h, size_t* bytes) {
+    if (!h || !bytes) return fail(VTTS_ERR_INVALID, "null argument");
+    *bytes = h->blob_bytes;
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_bytes, vtts_stream stream) {
+    if (!h || !dev_blob) return fail(VTTS_ERR_INVALID, "null argument");
+    if (blob_bytes < h->blob_bytes) return fail(VTTS_ERR_NOMEM, "blob too small: %zu < %zu", blob_bytes, h->blob_bytes);
+    if ((reinterpret_cast<uintptr_t>(dev_blob) & 255) != 0) return fail(VTTS_ERR_INVALID, "blob must be 256-B aligned");
+    for (auto& l : h->layers)
+        if (!l.have_w || !l.have_b) return fail(VTTS_ERR_MISSING, "parameter %s/%s was never set", l.key.c_str(), l.have_w ? "b" : "w");
+    std::vector<char> host(h->blob_bytes, 0);
+    for (auto& l : h->layers) {
+        memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
+        memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
+        if (l.has_wp) conv1d_f32_mfma_pack(l.w.data(), l.cin, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));
+    }
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(dev_blob, host.data(), h->blob_bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // `host` dies at return
+    h->blob = static_cast<char*>(dev_blob);
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_bind_packed(vtts_hifigan* h, void* dev_blob, size_t blob_bytes) {
+    if (!h || !dev_blob) return fail(VTTS_ERR_INVALID, "null argument");
+    if (blob_bytes < h->blob_bytes) return fail(VTTS_ERR_NOMEM, "blob too small: %zu < %zu", blob_bytes, h->blob_bytes);
+    if ((reinterpret_cast<uintptr_t>(dev_blob) & 255) != 0) return fail(VTTS_ERR_INVALID, "blob must be 256-B aligned");
+    h->blob = static_cast<char*>(dev_blob);
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, size_t* bytes) {
+    if (!h || !bytes) return fail(VTTS_ERR_INVALID, "null argument");
+    if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive");
+    const int mb = pick_microbatch(h, B, T);
+    *bytes = 4 * align_up(max_act_elems(h, T) * (size_t)mb * sizeof(float), 256);
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev, void* workspace,
+                                  size_t workspace_bytes, vtts_stream stream) {
+    if (!h || !mel_dev || !wav_dev) return fail(VTTS_ERR_INVALID, "null argument");
+    return forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream), Taps{});
+}
+
+VTTS_API int vtts_hifigan_tap_elems(const vtts_hifigan* h, const char* tap, int B, int T, size_t* elems) {
+    if (!h || !tap || !elems) return fail(VTTS_ERR_INVALID, "null argument");
+    const vtts_hifigan_cfg& c = h->cfg;
+    if (!strcmp(tap, "pre_tanh")) {
+        *elems = (size_t)B * h->hop * T;
+        return VTTS_OK;
+    }
+    if (!strcmp(tap, "conv_pre")) {
+        *elems = (size_t)B * c.upsample_initial_channel * T;
+        return VTTS_OK;
+    }
+    if (!strncmp(tap, "ups_", 4) || !strncmp(tap, "mrf_", 4)) {
+        const int i = atoi(tap + 4);
+        if (i < 0 || i >= c.num_upsamples) return fail(VTTS_ERR_INVALID, "tap stage %d out of range", i);
+        long L = T;
+        for (int q = 0; q <= i; ++q) L *= c.upsample_rates[q];
+        *elems = (size_t)B * (c.upsample_initial_channel >> (i + 1)) * L;
+        return VTTS_OK;
+    }
+    return fail(VTTS_ERR_INVALID, "unknown tap '%s'", tap);
+}
+
+VTTS_API int vtts_hifigan_forward_tap(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev, void* workspace,
+                                      size_t workspace_bytes, vtts_stream stream, const char* tap, float* tap_dev) {
+    if (!h || !mel_dev || !wav_dev || !tap || !tap_dev) return fail(VTTS_ERR_INVALID, "null argument");
+    size_t n = 0;
+    int rc = vtts_hifigan_tap_elems(h, tap, B, T, &n);
+    if (rc) return rc;
+    Taps t;
+    t.name = tap;
+    t.out = tap_dev;
+    t.Bfull = B;
+    return forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream), t);
+}
+
+VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev, int B, int L, float slope_in,
+                                     const float* res_dev, float* y_dev, vtts_stream stream) {
+    if (!h || !key || !x_dev || !y_dev) return fail(VTTS_ERR_INVALID, "null argument");
+    if (!h->blob) return fail(VTTS_ERR_STATE, "run_module() before pack()/bind_packed()");
+    if (B <= 0 || L <= 0) return fail(VTTS_ERR_INVALID, "B and L must be positive");
+    Layer* l = find_layer(h, key);
+    if (!l) return fail(VTTS_ERR_INVALID, "unknown module '%s'", key);
+    const bool is_pre = (l == &h->layers[h->idx_pre]);
+    const bool is_post = (l == &h->layers[h->idx_post]);
+    Act x = is_pre ? Act{x_dev, (long)L * l->cin, 1, l->cin} : Act{x_dev, (long)l->cin * L, L, 1};
+    return run_layer(h, *l, x, B, L, slope_in, res_dev, y_dev, ACC_STORE, 1.f, is_post ? 1 : 0, nullptr,
+                     static_cast<hipStream_t>(stream));
+}
+
+VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
+    if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
+    if (!strcmp(name, "kernels")) {
+        if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "kernels must be 0 (auto) or 1 (generic)");
+        h->opt_kernels = value;
+    } else if (!strcmp(name, "microbatch")) {
+        if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
+        h->opt_microbatch = value;
+    } else if (!strcmp(name, "profile")) {
+        h->opt_profile = value ? 1 : 0;
+    } else {
+        return fail(VTTS_ERR_INVALID, "unknown option '%s'", name);
+    }
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, int64_t* value) {
+    if (!h || !name || !value) return fail(VTTS_ERR_INVALID, "null argument");
+    if (!strcmp(name, "kernels")) *value = h->opt_kernels;
+    else if (!strcmp(name, "microbatch")) *value = h->opt_microbatch;
+    else if (!strcmp(name, "profile")) *value = h->opt_profile;
+    else if (!strcmp(name, "hop")) *value = h->hop;
+    else if (!strcmp(name, "profile_C")) *value = h->prof_C;
+    else if (!strcmp(name, "profile_K")) *value = h->prof_K;
+    else return fail(VTTS_ERR_INVALID, "unknown option '%s'", name);
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_hifigan_profile_read(vtts_hifigan* h, double* resblock_ms, int64_t* launches, double* resblock_flops,
+                                       int reset) {
+    if (!h) return fail(VTTS_ERR_INVALID, "null argument");
+    double ms = 0.0;
+    for (size_t i = 0; i < h->prof_used; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventSynchronize(h->prof_events[i].second));
+        HIP_TRY(hipEventElapsedTime(&t, h->prof_events[i].first, h->prof_events[i].second));
+        ms += t;
+    }
+    if (resblock_ms) *resblock_ms = ms;
+    if (launches) *launches = (int64_t)h->prof_used;
+    if (resblock_flops) *resblock_flops = h->prof_flops;
+    if (reset) {
+        h->prof_used = 0;
+        h->prof_flops = 0.0;
+    }
+    return VTTS_OK;
+}
+
+VTTS_API const char* vtts_hifigan_profile_kernel(const vtts_hifigan* h) { return h ? h->prof_name.c_str() : ""; }

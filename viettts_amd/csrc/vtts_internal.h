@@ -1,0 +1,58 @@
+// Internal declarations shared by the engine and the kernel translation units.
+// gfx950 only: wave64, MFMA, 160 KiB LDS.  No portability layer on purpose.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vtts {
+
+// How a convolution's result is combined with what is already in memory.  This is where
+// ResBlock1's residual (model.py:50 `x = xt + x`) and the MRF mean (model.py:115-121
+// `xs = rb0; xs += rb1; xs += rb2; x = xs / 3`) are fused into the producing kernel.
+//   v = acc + bias;  if (res) v = v + res[i];
+//   ACC_STORE : out[i] = v
+//   ACC_ADD   : out[i] = out[i] + v
+//   ACC_MEAN  : out[i] = (out[i] + v) / div      (true division, as the reference)
+enum AccMode : int { ACC_STORE = 0, ACC_ADD = 1, ACC_MEAN = 2 };
+
+struct ConvArgs {
+    const float* x;      // input activations
+    long x_sb, x_sc, x_st;  // element strides of x: batch, channel, time  (NCW: C*L, L, 1)
+    const float* w;      // plain weights, Haiku layout [K][Cin][Cout]  (convT: [K][Cout][Cin])
+    const void* wp;      // MFMA-packed weights (or nullptr)
+    const float* bias;   // [Cout]
+    const float* res;    // optional residual [B][Cout][L] (may alias y) or nullptr
+    float* y;            // output [B][Cout][Lout]
+    int B, Cin, Cout, K;
+    int dil, pad;        // convolution: rate and symmetric zero pad
+    int stride, pad_a;   // transposed convolution: stride and left pad of the zero-stuffed input
+    int L;               // input length (time)
+    int Lout;            // output length
+    float slope_in;      // LeakyReLU slope applied to x on load (1.0f = identity)
+    int acc_mode;        // AccMode
+    float div;           // divisor for ACC_MEAN
+    int tanh_out;        // apply tanh to the result (conv_post)
+    float* pre_act;      // optional copy of the pre-tanh value (same indexing as y) or nullptr
+};
+
+// ---- generic (any shape) fp32 kernels: kernels_generic.hip -------------------------------
+hipError_t launch_conv1d_generic(const ConvArgs& a, hipStream_t s);
+hipError_t launch_convT1d_generic(const ConvArgs& a, hipStream_t s);
+
+// ---- fp32 MFMA implicit-GEMM convolution (Cin == Cout in {32,64,128,256}, K in {3,7,11}) --
+// Returns false in *supported if the shape has no MFMA instantiation.
+bool conv1d_f32_mfma_supported(int C, int K, int dil, int L);
+size_t conv1d_f32_mfma_packed_floats(int C, int K);
+// host-side re-layout: Haiku [K][Cin][Cout] -> MFMA A-fragment order (see kernels_f32_mfma.hip)
+void conv1d_f32_mfma_pack(const float* w_hk, int C, int K, float* out);
+hipError_t launch_conv1d_f32_mfma(const ConvArgs& a, hipStream_t s);
+const char* conv1d_f32_mfma_kernel_name(int C, int K);
+
+// ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
+bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
+size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K);
+void convT1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, float* out);
+hipError_t launch_convT1d_f32_mfma(const ConvArgs& a, hipStream_t s);
+
+}  // namespace vtts

@@ -1,0 +1,147 @@
+"""Data-parallel sharding of the mel->waveform path across the GPUs of one node.
+
+The reference has no inference parallelism at all (``mel2wave`` is single-utterance, single-device;
+its only parallel code is the TPU ``pmap`` trainer, vietTTS/nat/acoustic_tpu_trainer.py:38-53, out of
+scope).  The path shards naturally: utterances are independent, and time chunks of a
+long utterance are independent given a 13-frame mel halo.  So: one process per GPU, the packed weight
+blob is broadcast ONCE from rank 0 (RCCL over xGMI when the backend is "nccl"; gloo on CPU in tests),
+and there is NO data-path collective.  Results stay on the rank that produced them unless the caller
+asks for a gather.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+HALO_FRAMES = 13  # receptive field of the generator is +-12.71 mel frames
+
+
+@dataclass(frozen=True)
+class RankInfo:
+    rank: int
+    world: int
+    local_rank: int
+
+
+def rank_info() -> RankInfo:
+    """RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run exports them (1-process default)."""
+    return RankInfo(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_process_group(backend: Optional[str] = None) -> RankInfo:
+    """One process per GPU.  backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests."""
+    info = rank_info()
+    if info.world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            torch.cuda.set_device(info.local_rank)
+        dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world)
+    return info
+
+
+# ---------------------------------------------------------------------------------------------------
+# partitioning (pure functions; identical on every rank, so no communication is needed to agree)
+# ---------------------------------------------------------------------------------------------------
+def shard_utterances(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Greedy longest-first assignment of utterance indices to ranks by total frame count.
+    Deterministic (ties broken by index); every index appears exactly once."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda q: (load[q], q))
+        out[r].append(i)
+        load[r] += int(lengths[i])
+    for r in range(world):
+        out[r].sort()
+    return out
+
+
+@dataclass(frozen=True)
+class Chunk:
+    index: int
+    t0: int  # first mel frame whose samples this chunk keeps
+    t1: int  # one past the last
+    lo: int  # first mel frame fed to the generator (t0 - halo, clipped at the utterance start)
+    hi: int  # one past the last frame fed (t1 + halo, clipped at the end)
+
+    @property
+    def keep_from(self) -> int:
+        """Frames to drop from the front of the chunk's output."""
+        return self.t0 - self.lo
+
+    @property
+    def frames(self) -> int:
+        return self.hi - self.lo
+
+
+def plan_chunks(T: int, chunk_frames: int, halo: int = HALO_FRAMES) -> List[Chunk]:
+    """Cut ``T`` frames into chunks of ``chunk_frames`` kept frames + ``halo`` context frames per
+    side.  At true utterance edges there is no halo: the generator's own zero padding
+    (get_padding, vietTTS/hifigan/model.py:8-10) applies there, exactly as un-chunked."""
+    if T < 1 or chunk_frames < 1 or halo < 0:
+        raise ValueError("T, chunk_frames must be >= 1 and halo >= 0")
+    out = []
+    t0, i = 0, 0
+    while t0 < T:
+        t1 = min(T, t0 + chunk_frames)
+        out.append(Chunk(i, t0, t1, max(0, t0 - halo), min(T, t1 + halo)))
+        t0, i = t1, i + 1
+    return out
+
+
+def shard_chunks(chunks: Sequence[Chunk], world: int) -> List[List[Chunk]]:
+    """chunk c -> rank c mod world."""
+    return [[c for c in chunks if c.index % world == r] for r in range(world)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# the one collective: weight broadcast at start-up
+# ---------------------------------------------------------------------------------------------------
+def broadcast_packed_weights(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """Broadcast the packed weight blob (uint8 tensor, identical size on every rank) in place."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(blob, src=src)
+    return blob
+
+
+def setup_generator_dp(gen, params_fn, info: Optional[RankInfo] = None):
+    """Rank 0 builds/loads + packs the weights, every other rank receives the packed blob.
+    ``params_fn()`` returns the Haiku parameter dict and is only called on rank 0."""
+    info = info or rank_info()
+    if info.world == 1 or info.rank == 0:
+        gen.load_params(params_fn())
+        blob = gen.packed_blob()
+    else:
+        blob = torch.empty(gen.packed_bytes, dtype=torch.uint8, device=gen.device)
+    if info.world > 1:
+        broadcast_packed_weights(blob, 0)
+        if info.rank != 0:
+            gen.adopt_packed(blob)
+    return gen
+
+
+def gather_to_rank0(local: torch.Tensor, info: Optional[RankInfo] = None) -> Optional[List[torch.Tensor]]:
+    """Optional end-of-job gather for a single-writer CLI (not on the data path)."""
+    info = info or rank_info()
+    if info.world == 1:
+        return [local]
+    sizes = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(info.world)]
+    dist.all_gather(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=local.device))
+    mx = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros(mx, dtype=local.dtype, device=local.device)
+    pad[: local.numel()] = local.reshape(-1)
+    bufs = [torch.empty_like(pad) for _ in range(info.world)] if info.rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if info.rank != 0:
+        return None
+    return [b[: int(s.item())] for b, s in zip(bufs, sizes)]

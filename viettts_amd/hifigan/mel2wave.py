@@ -1,0 +1,71 @@
+"""Drop-in for ``vietTTS.hifigan.mel2wave.mel2wave`` (vietTTS/hifigan/mel2wave.py:20-41).
+
+Same name, same positional signature, same files read (``assets/hifigan/config.json`` relative to
+the CWD, ``./assets/infore/hifigan/hk_hifi.pickle``), same result (host ``np.float32`` array,
+``jnp.squeeze``-d: ``[256*T]`` for a single utterance, ``[B, 256*T]`` for a batch).  Differences,
+none of them observable in the output: the config and the 55.7 MB pickle are read once and cached
+(the reference re-reads both on every call; ``reload()`` drops the cache), and the generator runs on
+MI355X through the HIP library instead of un-jitted XLA-CPU ops.
+
+Errors follow the reference: a missing config / checkpoint raises ``FileNotFoundError``; a wrong
+mel shape raises ``ValueError``.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from .config import FLAGS, HifiganConfig
+from .generator import Generator
+from .weights import load_haiku_pickle
+
+_CACHE: dict = {}
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("mel2wave needs an MI355X visible to PyTorch-ROCm; there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def reload() -> None:
+    """Forget cached config/weights (the reference has no cache: it re-reads per call)."""
+    for g in _CACHE.values():
+        g.close()
+    _CACHE.clear()
+
+
+def _generator(dtype: str = "f32") -> Generator:
+    config_file = str(FLAGS.config_file)  # CWD-relative, as mel2wave.py:21
+    ckpt = FLAGS.ckpt_dir / "hk_hifi.pickle"  # mel2wave.py:35
+    if not os.path.exists(config_file):
+        raise FileNotFoundError(config_file)
+    if not os.path.exists(ckpt):
+        raise FileNotFoundError(str(ckpt))
+    dev = _device()
+    key = (os.path.abspath(config_file), os.path.getmtime(config_file), os.path.abspath(ckpt), os.path.getmtime(ckpt), str(dev), dtype)
+    g = _CACHE.get(key)
+    if g is None:
+        cfg = HifiganConfig.from_json(config_file)
+        g = Generator(cfg, device=dev, dtype=dtype)
+        g.load_params(load_haiku_pickle(ckpt))
+        _CACHE[key] = g
+    return g
+
+
+def mel2wave(mel):
+    """mel: ``[B, T, 80]`` float32 log-mel, NWC (numpy array, torch tensor, or anything
+    ``np.asarray`` accepts) -> waveform, float32 numpy, squeezed."""
+    g = _generator()
+    if isinstance(mel, torch.Tensor):
+        m = mel.detach().to(device=g.device, dtype=torch.float32)
+    else:
+        m = torch.from_numpy(np.ascontiguousarray(np.asarray(mel), dtype=np.float32)).to(g.device)
+    if m.dim() != 3:
+        raise ValueError(f"mel must be [B, T, {g.cfg.num_mels}], got shape {tuple(m.shape)}")
+    wav = g(m)
+    # jnp.squeeze + jax.device_get (mel2wave.py:39-40); .cpu() synchronises the stream
+    return np.squeeze(wav.cpu().numpy())

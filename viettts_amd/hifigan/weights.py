@@ -72,11 +72,10 @@ def conv_specs(cfg: HifiganConfig) -> List[ConvSpec]:
         ch = cfg.stage_channels(i)
         for k, dil in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
             blk = []
-            for z in range(3):
+            for z in range(3):  # ResBlock1.__call__ runs convs1_z then convs2_z (model.py:45-49)
                 blk.append(
                     ConvSpec(f"generator/~/res_block1_{n}/~/convs1_{z}", f"resblocks.{n}.convs1.{z}", "conv", ch, ch, int(k), int(dil[z]))
                 )
-            for z in range(3):
                 blk.append(
                     ConvSpec(f"generator/~/res_block1_{n}/~/convs2_{z}", f"resblocks.{n}.convs2.{z}", "conv", ch, ch, int(k), 1)
                 )
