@@ -81,6 +81,34 @@ def default_lib_path() -> Path:
 
 
 _LIB: Optional[C.CDLL] = None
+_HIP_RT = None
+
+
+def _load_hip_runtime():
+    """libvtts_hifigan.so carries no DT_NEEDED for the HIP runtime (csrc/build.py): bind it to the
+    ONE runtime the process uses.  With PyTorch-ROCm that is torch's bundled libamdhip64.so — streams
+    and device pointers handed across the C ABI come from it — otherwise the system one."""
+    global _HIP_RT
+    if _HIP_RT is not None:
+        return _HIP_RT
+    cands = []
+    try:
+        import torch  # noqa: F401  (loads its runtime first)
+
+        cands.append(Path(torch.__file__).resolve().parent / "lib" / "libamdhip64.so")
+    except Exception:
+        pass
+    cands += [Path("/opt/rocm/lib/libamdhip64.so")]
+    err = None
+    for c in cands:
+        if c.exists():
+            try:
+                _HIP_RT = C.CDLL(str(c), mode=C.RTLD_GLOBAL)
+                return _HIP_RT
+            except OSError as e:  # pragma: no cover
+                err = e
+    raise OSError(f"no HIP runtime (libamdhip64) could be loaded: {err}")
+
 
 
 def load(path=None) -> C.CDLL:
@@ -94,6 +122,7 @@ def load(path=None) -> C.CDLL:
             f"HIP extension {p} not found — build it with `python -m viettts_amd.csrc.build` "
             "(there is no CPU fallback on the product path)"
         )
+    _load_hip_runtime()
     lib = C.CDLL(str(p))
     vp, cp, sz, i64 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64
     fp = C.POINTER(C.c_float)

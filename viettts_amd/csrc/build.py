@@ -69,7 +69,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out), *map(str, objs)]
+    # Link WITHOUT a DT_NEEDED on libamdhip64: PyTorch-ROCm bundles its own HIP runtime
+    # (torch/lib/libamdhip64.so, a different soname from /opt/rocm's libamdhip64.so.7), and a process
+    # must not end up with two runtimes.  The hip* symbols stay undefined here and bind at dlopen to
+    # the runtime the host already loaded (viettts_amd/_lib.py promotes it to the global scope; a C
+    # host links -lamdhip64 itself).
+    cxx = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(cxx):
+        cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    cmd = [cxx, "-shared", "-fPIC", "-o", str(out), *map(str, objs)]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
