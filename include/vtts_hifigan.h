@@ -141,6 +141,8 @@ int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev
  * Engine options (tests / benchmarks):
  *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
  *   "microbatch" utterances processed per pass through the network (0 = auto)
+ *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
+ *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
  */
 int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value);
 int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, int64_t* value);

@@ -63,9 +63,10 @@ def _res_conv_cases():
     return out
 
 
-@pytest.mark.parametrize("kernels", [0, 1], ids=["mfma", "generic"])
+@pytest.mark.parametrize("kernels", [(0, 1), (0, 2), (1, 0)], ids=["mfma-wide", "mfma-narrow", "generic"])
 @pytest.mark.parametrize("spec", _res_conv_cases(), ids=lambda s: f"C{s.cin}k{s.k}d{s.dilation}")
 def test_resblock_conv_kat(gen_v1, v1_params, dev, spec, kernels):
+    kernels, tiles = kernels
     rng = np.random.default_rng(spec.cin * 1000 + spec.k * 10 + spec.dilation)
     B, L = 2, 300 if spec.cin >= 128 else 1000  # ragged: not a multiple of any time tile
     x = rng.standard_normal((B, spec.cin, L)).astype(np.float32) * 2.0
@@ -74,11 +75,13 @@ def test_resblock_conv_kat(gen_v1, v1_params, dev, spec, kernels):
     xt = orc.leaky_relu(_nwc(x).astype(np.float64), 0.1)
     ref = orc.conv1d(xt, w.astype(np.float64), b.astype(np.float64), spec.dilation, orc.get_padding(spec.k, spec.dilation)) + _nwc(res)
     gen_v1.set_option("kernels", kernels)
+    gen_v1.set_option("tiles", tiles)
     try:
         y = gen_v1.run_module(spec.key, torch.from_numpy(x).to(dev), 0.1, torch.from_numpy(res).to(dev))
         torch.cuda.synchronize()
     finally:
         gen_v1.set_option("kernels", 0)
+        gen_v1.set_option("tiles", 0)
     err = np.abs(_nwc(y.cpu().numpy()) - ref).max()
     assert err < TIGHT, f"{spec.key} ({'generic' if kernels else 'mfma'}): max|err| = {err}"
 
@@ -236,7 +239,7 @@ def test_receptive_field_halo(gen_v1, dev):
     chunk = gen_v1(mel[:, t0 - halo : t1 + halo].contiguous())
     a = full[:, 256 * t0 : 256 * t1]
     b = chunk[:, 256 * halo : 256 * (halo + t1 - t0)]
-    assert (a - b).abs().max().item() < 1e-6
+    assert (a - b).abs().max().item() < 5e-6  # different tile/stage shapes -> fp32 reassociation only
     # and a 12-frame halo is NOT enough (the field really is that wide)
     chunk12 = gen_v1(mel[:, t0 - 12 : t1 + 12].contiguous())
     b12 = chunk12[:, 256 * 12 : 256 * (12 + t1 - t0)]

@@ -45,18 +45,28 @@ def lib_path() -> Path:
     return LIBDIR / LIBNAME
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), libname: str = LIBNAME) -> Path:
+    """extra_flags/libname build an experiment variant next to the product library (A/B runs)."""
+    global FLAGS
     LIBDIR.mkdir(parents=True, exist_ok=True)
     OBJDIR.mkdir(parents=True, exist_ok=True)
-    stamp = LIBDIR / (LIBNAME + ".sha256")
+    stamp = LIBDIR / (libname + ".sha256")
+    base_flags = list(FLAGS)
+    FLAGS = base_flags + list(extra_flags)
+    try:
+        return _build(force, verbose, stamp, LIBDIR / libname, libname)
+    finally:
+        FLAGS = base_flags
+
+
+def _build(force, verbose, stamp, out, libname) -> Path:
     dig = _digest()
-    out = lib_path()
     if not force and out.exists() and stamp.exists() and stamp.read_text().strip() == dig:
         return out
     hipcc = _hipcc()
 
     def compile_one(src: str) -> Path:
-        obj = OBJDIR / (Path(src).stem + ".o")
+        obj = OBJDIR / (Path(src).stem + "." + libname + ".o")
         cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -91,5 +101,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--define", action="append", default=[], help="extra -D flags for an experiment variant")
+    ap.add_argument("--libname", default=LIBNAME)
     a = ap.parse_args()
-    print(build(a.force, a.verbose))
+    print(build(a.force, a.verbose, ["-D" + d for d in a.define], a.libname))

@@ -78,6 +78,7 @@ struct vtts_hifigan {
     int64_t opt_kernels = 0;         // 0 auto, 1 generic only
     int64_t opt_microbatch = 0;      // 0 auto
     int64_t opt_profile = 0;
+    int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     // profiling of the dominant kernel class
     int prof_C = 0, prof_K = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -138,31 +139,37 @@ int build_layers(vtts_hifigan* h) {
     // blob layout: per layer plain weights, bias, optional MFMA-packed weights; 256-B aligned
     size_t off = 0;
     double best_flops = -1.0;
-    long len = 1;  // output positions per mel frame
     for (auto& l : h->layers) {
         l.off_w = off;
         off = align_up(off + (size_t)l.k * l.cin * l.cout * sizeof(float), 256);
         l.off_b = off;
         off = align_up(off + (size_t)l.cout * sizeof(float), 256);
-        if (l.kind == KIND_CONVT) len *= l.stride;
-        if (h->dtype == VTTS_F32 && l.kind == KIND_CONV && l.cin == l.cout &&
-            conv1d_f32_mfma_supported(l.cin, l.k, l.dil, 4)) {
+        const bool is_pre = (&l == &h->layers[h->idx_pre]);
+        if (h->dtype == VTTS_F32 && l.kind == KIND_CONV && conv1d_f32_mfma_supported(l.cin, l.cout, l.k, l.dil, 4, is_pre)) {
             l.has_wp = true;
-            l.wp_floats = conv1d_f32_mfma_packed_floats(l.cin, l.k);
+            l.wp_floats = conv1d_f32_mfma_packed_floats(l.cin, l.cout, l.k);
             l.off_wp = off;
             off = align_up(off + l.wp_floats * sizeof(float), 256);
-            // dominant kernel class = the (C, K) with the most FLOPs per mel frame
-            double fl = 0.0;
-            long len2 = 1;
-            for (auto& m : h->layers) {
-                if (m.kind == KIND_CONVT) len2 *= m.stride;
-                if (m.kind == KIND_CONV && m.cin == l.cin && m.k == l.k && m.cin == m.cout) fl += 2.0 * len2 * m.cin * m.cout * m.k;
+            if (!is_pre) {
+                // dominant kernel class = the ResBlock (C, K) with the most FLOPs per mel frame
+                double fl = 0.0;
+                long len2 = 1;
+                for (auto& m : h->layers) {
+                    if (m.kind == KIND_CONVT) len2 *= m.stride;
+                    if (m.kind == KIND_CONV && m.cin == l.cin && m.k == l.k && m.cin == m.cout) fl += 2.0 * len2 * m.cin * m.cout * m.k;
+                }
+                if (fl > best_flops) {
+                    best_flops = fl;
+                    h->prof_C = l.cin;
+                    h->prof_K = l.k;
+                }
             }
-            if (fl > best_flops) {
-                best_flops = fl;
-                h->prof_C = l.cin;
-                h->prof_K = l.k;
-            }
+        } else if (h->dtype == VTTS_F32 && l.kind == KIND_CONVT &&
+                   convT1d_f32_mfma_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, 4)) {
+            l.has_wp = true;
+            l.wp_floats = convT1d_f32_mfma_packed_floats(l.cin, l.cout, l.k);
+            l.off_wp = off;
+            off = align_up(off + l.wp_floats * sizeof(float), 256);
         }
     }
     h->blob_bytes = off;
@@ -210,15 +217,26 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
     a.div = div;
     a.tanh_out = tanh_out;
     a.pre_act = pre_act;
+    a.tile_pref = (int)h->opt_tiles;
 
     hipError_t e;
+    const bool ncw = x.st == 1 && x.sc == L && (x.sb % 4) == 0;
+    const bool want_mfma = h->opt_kernels == 0 && l.has_wp;
     if (l.kind == KIND_CONVT) {
-        e = launch_convT1d_generic(a, s);
+        if (want_mfma && ncw && !res && acc_mode == ACC_STORE && convT1d_f32_mfma_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, L))
+            e = launch_convT1d_f32_mfma(a, s);
+        else
+            e = launch_convT1d_generic(a, s);
+    } else if (tanh_out) {
+        if (h->opt_kernels == 0 && ncw && !res && acc_mode == ACC_STORE && conv_post_fast_supported(l.cin, l.cout, l.k, L))
+            e = launch_conv_post_fast(a, s);
+        else
+            e = launch_conv1d_generic(a, s);
     } else {
-        const bool mfma = h->opt_kernels == 0 && l.has_wp && x.st == 1 && x.sc == L && (x.sb % 4) == 0 &&
-                          conv1d_f32_mfma_supported(l.cin, l.k, l.dil, L) && !tanh_out;
+        const bool nwc = x.sc == 1 && x.st == l.cin;
+        const bool mfma = want_mfma && (ncw || nwc) && conv1d_f32_mfma_supported(l.cin, l.cout, l.k, l.dil, L, nwc);
         if (mfma) {
-            const bool prof = h->opt_profile && l.cin == h->prof_C && l.k == h->prof_K;
+            const bool prof = h->opt_profile && l.cin == h->prof_C && l.cout == h->prof_C && l.k == h->prof_K;
             if (prof) {
                 if (h->prof_used == h->prof_events.size()) {
                     hipEvent_t e0, e1;
@@ -398,8 +416,8 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
 VTTS_API void vtts_hifigan_destroy(vtts_hifigan* h) {
     if (!h) return;
     for (auto& p : h->prof_events) {
-        hipEventDestroy(p.first);
-        hipEventDestroy(p.second);
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
     }
     delete h;
 }
@@ -469,7 +487,10 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
     for (auto& l : h->layers) {
         memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
         memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
-        if (l.has_wp) conv1d_f32_mfma_pack(l.w.data(), l.cin, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));
+        if (l.has_wp && l.kind == KIND_CONV)
+            conv1d_f32_mfma_pack(l.w.data(), l.cin, l.cout, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));
+        else if (l.has_wp)
+            convT1d_f32_mfma_pack(l.w.data(), l.cin, l.cout, l.k, l.stride, l.pad_a, reinterpret_cast<float*>(host.data() + l.off_wp));
     }
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(dev_blob, host.data(), h->blob_bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
@@ -557,6 +578,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "microbatch")) {
         if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
         h->opt_microbatch = value;
+    } else if (!strcmp(name, "tiles")) {
+        if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "tiles must be 0 (auto), 1 (wide) or 2 (narrow)");
+        h->opt_tiles = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
     } else {
@@ -570,6 +594,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     if (!strcmp(name, "kernels")) *value = h->opt_kernels;
     else if (!strcmp(name, "microbatch")) *value = h->opt_microbatch;
     else if (!strcmp(name, "profile")) *value = h->opt_profile;
+    else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
     else if (!strcmp(name, "hop")) *value = h->hop;
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;
     else if (!strcmp(name, "profile_K")) *value = h->prof_K;

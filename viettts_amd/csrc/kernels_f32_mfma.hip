@@ -1,8 +1,11 @@
-// fp32 implicit-GEMM dilated Conv1d on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+// fp32 implicit-GEMM convolutions on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// This kernel family is 96.8 % of the generator's FLOPs: the 72 ResBlock1 convolutions
-// (vietTTS/hifigan/model.py:21-28 convs1 with rate d, :33-40 convs2 with rate 1), C -> C with
-// C in {256,128,64,32}, K in {3,7,11}.
+//  * conv1d_f32_mfma_k   — dilated Conv1d.  The 72 ResBlock1 convolutions (96.8 % of the FLOPs;
+//                          vietTTS/hifigan/model.py:21-28 convs1 with rate d, :33-40 convs2) and
+//                          conv_pre (model.py:83, mel NWC in).
+//  * convT1d_f32_mfma_k  — the four ConvTranspose1d upsamplers in polyphase form (model.py:88-94,
+//                          SURVEY.md Appendix A.2): no zero-stuffing, every output phase uses exactly
+//                          its two live taps.
 //
 // GEMM view:  Y[co, t] = sum_{j,ci} W[j][ci][co] * f(X[ci, t + j*d - p])
 //   M = co (output channels)   N = t (time, the only long axis)   K = (tap j, input channel ci)
@@ -23,6 +26,10 @@
 //   * epilogue fuses bias, the ResBlock residual and the MRF accumulate/mean (device_common.h).
 #include "device_common.h"
 
+#ifndef VTTS_PIN_PREFETCH
+#define VTTS_PIN_PREFETCH 0
+#endif
+
 namespace vtts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,29 +37,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int round_up4(int v) { return (v + 3) & ~3; }
 constexpr int MAX_DIL = 5;  // resblock_dilation_sizes max in V1; larger rates fall back to the generic kernel
 
-template <int C_, int KS_, int MT_, int NT_, int WM_, int WN_, int CK_>
+// =================================================================================================
+// dilated Conv1d
+// =================================================================================================
+template <int CIN_, int COUT_, int KS_, int MT_, int NT_, int WM_, int WN_, int CK_, bool NWC_>
 struct ConvTile {
-    static constexpr int C = C_, KS = KS_, MT = MT_, NT = NT_, WM = WM_, WN = WN_, CK = CK_;
+    static constexpr int CIN = CIN_, COUT = COUT_, KS = KS_, MT = MT_, NT = NT_, WM = WM_, WN = WN_, CK = CK_;
+    static constexpr bool NWC = NWC_;                 // input is [B][L][CIN] (conv_pre reads the mel as given)
     static constexpr int MR = MT / WM / 32;           // 32x32 accumulator blocks per wave along M
     static constexpr int NR = NT / WN / 32;           // ... along N
-    static constexpr int PA = round_up4((KS - 1) / 2 * MAX_DIL);  // staged halo per side
+    static constexpr int PA = round_up4((KS - 1) / 2 * (NWC ? 1 : MAX_DIL));  // staged halo per side
     static constexpr int W = NT + 2 * PA;             // staged columns (multiple of 4)
-    static constexpr int RS = W;                      // LDS row stride in floats
-    static constexpr int NCH = C / CK;                // input-channel chunks
+    static constexpr int RS = NWC ? W + 1 : W;        // LDS row stride in floats (odd for the transposing stage)
+    static constexpr int NCH = CIN / CK;              // input-channel chunks
     static constexpr int CQ = CK / 8;                 // float4 A loads per tap per chunk
     static constexpr int NIT = KS * CQ;               // main-loop iterations per chunk
     static constexpr int LDS_BYTES = CK * RS * 4;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(MT % (WM * 32) == 0 && NT % (WN * 32) == 0, "tile/wave mismatch");
-    static_assert(C % MT == 0 && C % CK == 0 && CK % 8 == 0, "channel tiling");
+    static_assert(COUT % MT == 0 && CIN % CK == 0 && CK % 8 == 0, "channel tiling");
 };
 
-// Packed weight layout (floats): [mblk = C/32][chunk][j][cq][lane = 64][e = 4]
+// Packed weight layout (floats): [mblk = COUT/32][chunk][j][cq][lane = 64][e = 4]
 //   element = W_hk[j][ci = chunk*CK + 2*(4*cq + e) + (lane >> 5)][co = mblk*32 + (lane & 31)]
 // i.e. for k-step (j, cp = 4*cq + e) lane l holds A[i = l&31][k = l>>5] of the 32x32x2 MFMA.
 template <class T>
 __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
-    constexpr int C = T::C, KS = T::KS, MT = T::MT, NT = T::NT, WN = T::WN, CK = T::CK;
+    constexpr int COUT = T::COUT, MT = T::MT, NT = T::NT, WN = T::WN, CK = T::CK;
     constexpr int MR = T::MR, NR = T::NR, PA = T::PA, W = T::W, RS = T::RS, NCH = T::NCH, CQ = T::CQ, NIT = T::NIT;
 
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [CK][RS]
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
     for (int chunk = 0; chunk < NCH; ++chunk) {
         if (chunk) __syncthreads();  // all waves done reading the previous chunk
         // ---- stage CK input channels x W columns, LeakyReLU fused, zero outside [0, L) ----
-        {
+        if constexpr (!T::NWC) {
             constexpr int W4 = W / 4;
             const float* __restrict__ xc = xb + (long)(chunk * CK) * a.x_sc;
             for (int idx = tid; idx < CK * W4; idx += 256) {
@@ -114,6 +125,18 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
                 v.w = lrelu(v.w, slope);
                 *reinterpret_cast<float4*>(&xs[row * RS + 4 * c4]) = v;
             }
+        } else {
+            // time-major input [L][CIN]: coalesced reads along channels, transposing LDS writes
+            // (row stride RS is odd, so the stride-RS ds_write_b32 is conflict-free)
+            const float* __restrict__ xc = xb + chunk * CK;
+            for (int idx = tid; idx < CK * W; idx += 256) {
+                const int col = idx / CK;
+                const int row = idx - col * CK;
+                const int t = t0 - PA + col;
+                float v = 0.f;
+                if (t >= 0 && t < L) v = xc[(long)t * a.x_st + row];
+                xs[row * RS + col] = lrelu(v, slope);
+            }
         }
         __syncthreads();
 
@@ -126,6 +149,9 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
             const bool has_next = nxt < (long)NCH * NIT;
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = has_next ? wbase[mr][nxt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#if VTTS_PIN_PREFETCH
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top: a full iteration (16 MFMAs) of cover
+#endif
 
             const float* xrow = &xs[(cq * 8 + lh) * RS + colbase + j * dil];
 #pragma unroll
@@ -156,7 +182,7 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const long idx = ((long)b * C + co) * L + t;
+                    const long idx = ((long)b * COUT + co) * L + t;
                     epilogue_store(a, idx, acc[mr][nr][r] + a.bias[co]);
                 }
             }
@@ -165,11 +191,17 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
 }
 
 // ---- tile selection --------------------------------------------------------------------------
-//                        C   KS  MT   NT  WM WN CK
-template <int KS> using Tile256 = ConvTile<256, KS, 128, 128, 2, 2, 64>;
-template <int KS> using Tile128 = ConvTile<128, KS, 128, 128, 2, 2, 64>;
-template <int KS> using Tile64 = ConvTile<64, KS, 64, 128, 2, 2, 64>;
-template <int KS> using Tile32 = ConvTile<32, KS, 32, 256, 1, 4, 32>;
+//                                          CIN  COUT KS  MT   NT  WM WN CK  NWC
+template <int KS> using Tile256 = ConvTile<256, 256, KS, 128, 128, 2, 2, 64, false>;
+template <int KS> using Tile128 = ConvTile<128, 128, KS, 128, 128, 2, 2, 64, false>;
+template <int KS> using Tile64 = ConvTile<64, 64, KS, 64, 128, 2, 2, 64, false>;
+template <int KS> using Tile32 = ConvTile<32, 32, KS, 32, 256, 1, 4, 32, false>;
+using TilePre = ConvTile<80, 512, 7, 128, 64, 4, 1, 80, true>;  // conv_pre: mel [T][80] -> [512][T]
+// narrow time tiles for short inputs (batch-1 latency): same math, 4x / 2x more workgroups
+template <int KS> using Tile256S = ConvTile<256, 256, KS, 128, 32, 4, 1, 64, false>;
+template <int KS> using Tile128S = ConvTile<128, 128, KS, 128, 64, 2, 2, 64, false>;
+template <int KS> using Tile64S = ConvTile<64, 64, KS, 64, 64, 2, 2, 64, false>;
+template <int KS> using Tile32S = ConvTile<32, 32, KS, 32, 128, 1, 4, 32, false>;
 
 template <class T>
 static hipError_t launch_tile(const ConvArgs& a, hipStream_t s) {
@@ -180,7 +212,7 @@ static hipError_t launch_tile(const ConvArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid((a.L + T::NT - 1) / T::NT, T::C / T::MT, a.B);
+    dim3 grid((a.L + T::NT - 1) / T::NT, T::COUT / T::MT, a.B);
     hipLaunchKernelGGL(conv1d_f32_mfma_k<T>, grid, dim3(256), T::LDS_BYTES, s, a);
     return hipGetLastError();
 }
@@ -195,22 +227,26 @@ static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-bool conv1d_f32_mfma_supported(int C, int K, int dil, int L) {
-    if (!(C == 256 || C == 128 || C == 64 || C == 32)) return false;
+static bool is_pre_shape(int Cin, int Cout, int K, int dil) { return Cin == 80 && Cout == 512 && K == 7 && dil == 1; }
+
+bool conv1d_f32_mfma_supported(int Cin, int Cout, int K, int dil, int L, bool nwc) {
+    if (nwc) return is_pre_shape(Cin, Cout, K, dil);
+    if (Cin != Cout) return false;
+    if (!(Cin == 256 || Cin == 128 || Cin == 64 || Cin == 32)) return false;
     if (!(K == 3 || K == 7 || K == 11)) return false;
     if (dil < 1 || dil > MAX_DIL) return false;
     if (L % 4 != 0) return false;  // float4 staging
     return true;
 }
 
-static int chunk_of(int C) { return C >= 64 ? 64 : 32; }
+static int chunk_of(int Cin) { return Cin == 80 ? 80 : (Cin >= 64 ? 64 : 32); }
 
-size_t conv1d_f32_mfma_packed_floats(int C, int K) { return (size_t)C * C * K; }
+size_t conv1d_f32_mfma_packed_floats(int Cin, int Cout, int K) { return (size_t)Cin * Cout * K; }
 
-void conv1d_f32_mfma_pack(const float* w_hk, int C, int K, float* out) {
-    const int CK = chunk_of(C), NCH = C / CK, CQ = CK / 8;
+void conv1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, float* out) {
+    const int CK = chunk_of(Cin), NCH = Cin / CK, CQ = CK / 8;
     size_t o = 0;
-    for (int mblk = 0; mblk < C / 32; ++mblk)
+    for (int mblk = 0; mblk < Cout / 32; ++mblk)
         for (int chunk = 0; chunk < NCH; ++chunk)
             for (int j = 0; j < K; ++j)
                 for (int cq = 0; cq < CQ; ++cq)
@@ -218,30 +254,330 @@ void conv1d_f32_mfma_pack(const float* w_hk, int C, int K, float* out) {
                         for (int e = 0; e < 4; ++e) {
                             const int ci = chunk * CK + 2 * (4 * cq + e) + (lane >> 5);
                             const int co = mblk * 32 + (lane & 31);
-                            out[o++] = w_hk[((size_t)j * C + ci) * C + co];
+                            out[o++] = w_hk[((size_t)j * Cin + ci) * Cout + co];
                         }
 }
 
+// workgroups the wide tile would launch; below ~1.5 per CU the narrow tile wins (measured at B=1)
+static long wide_wgs(const ConvArgs& a, int NT, int mtiles) { return ((long)(a.L + NT - 1) / NT) * mtiles * a.B; }
+
 hipError_t launch_conv1d_f32_mfma(const ConvArgs& a, hipStream_t s) {
+    if (a.x_st != 1) return launch_tile<TilePre>(a, s);
+    constexpr long MIN_WGS = 384;
+    auto narrow = [&](int NT, int mtiles) { return a.tile_pref == 2 || (a.tile_pref == 0 && wide_wgs(a, NT, mtiles) < MIN_WGS); };
     switch (a.Cin) {
-        case 256: return launch_ks<Tile256>(a, s);
-        case 128: return launch_ks<Tile128>(a, s);
-        case 64: return launch_ks<Tile64>(a, s);
-        case 32: return launch_ks<Tile32>(a, s);
+        case 256: return narrow(128, 2) ? launch_ks<Tile256S>(a, s) : launch_ks<Tile256>(a, s);
+        case 128: return narrow(128, 1) ? launch_ks<Tile128S>(a, s) : launch_ks<Tile128>(a, s);
+        case 64: return narrow(128, 1) ? launch_ks<Tile64S>(a, s) : launch_ks<Tile64>(a, s);
+        case 32: return narrow(256, 1) ? launch_ks<Tile32S>(a, s) : launch_ks<Tile32>(a, s);
     }
     return hipErrorInvalidValue;
 }
 
 const char* conv1d_f32_mfma_kernel_name(int C, int K) {
     static thread_local char buf[96];
-    snprintf(buf, sizeof(buf), "conv1d_f32_mfma_k<ConvTile<%d, %d", C, K);
+    snprintf(buf, sizeof(buf), "conv1d_f32_mfma_k<ConvTile<%d, %d, %d", C, C, K);
     return buf;
 }
 
-// transposed convolution on MFMA: not instantiated yet — the engine uses the generic polyphase kernel.
-bool convT1d_f32_mfma_supported(int, int, int, int, int, int) { return false; }
-size_t convT1d_f32_mfma_packed_floats(int, int, int) { return 0; }
-void convT1d_f32_mfma_pack(const float*, int, int, int, int, int, float*) {}
-hipError_t launch_convT1d_f32_mfma(const ConvArgs&, hipStream_t) { return hipErrorNotSupported; }
+// =================================================================================================
+// ConvTranspose1d, polyphase, k == 2*stride  (all four V1 upsamplers: (16,8),(16,8),(4,2),(4,2))
+// =================================================================================================
+// With pad_a from lax's "SAME" rule, output p = s*q + r reads input frames
+//   r <  s/2 : (q-1, q)        ("group" g = 0)
+//   r >= s/2 : (q,   q+1)      (g = 1)
+// through taps j = s*(g - 1 + m) + pad_a - r, m = 0,1.  Each group is a GEMM
+//   Yg[m' = co*SH + ph, q] = sum_{m, ci} Wg[m', (m, ci)] * f(X[ci, q + g - 1 + m]),  SH = s/2, r = g*SH + ph
+// A wave keeps both groups' accumulators, so the three distinct B fragments (frames q-1, q, q+1) are
+// read from LDS once and each lane ends up with s consecutive output samples of one channel:
+// SH = 4 -> two float4 stores (32 contiguous bytes), SH = 1 -> one float2 store; fully coalesced
+// although the GEMM's N axis (q) is strided by s in the output.
+template <int CIN_, int COUT_, int SH_, int MT_, int NT_, int WM_, int WN_, int CK_>
+struct ConvTTile {
+    static constexpr int CIN = CIN_, COUT = COUT_, SH = SH_, MT = MT_, NT = NT_, WM = WM_, WN = WN_, CK = CK_;
+    static constexpr int MP = COUT * SH;              // GEMM rows per group
+    static constexpr int MR = MT / WM / 32;
+    static constexpr int NR = NT / WN / 32;
+    static constexpr int PA = 4;                      // 1-frame halo, rounded up for float4 staging
+    static constexpr int W = NT + 2 * PA;
+    static constexpr int RS = W;
+    static constexpr int NCH = CIN / CK;
+    static constexpr int CQ = CK / 8;
+    static constexpr int LDS_BYTES = CK * RS * 4;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(MP % MT == 0 && CIN % CK == 0 && CK % 8 == 0, "tiling");
+    static_assert(SH == 4 || SH == 1, "stride 8 or 2");
+};
+
+// Packed layout (floats): [mblk = MP/32][chunk][cq][gm = 4][lane][e = 4],  gm = 2*g + m
+//   element = W_hk[j(g, m, ph)][co][ci]  with  m' = mblk*32 + (lane&31) = co*SH + ph,
+//             ci = chunk*CK + 2*(4*cq + e) + (lane>>5)
+template <class T>
+__global__ __launch_bounds__(256) void convT1d_f32_mfma_k(ConvArgs a) {
+    constexpr int COUT = T::COUT, SH = T::SH, MT = T::MT, NT = T::NT, WN = T::WN, CK = T::CK;
+    constexpr int MR = T::MR, NR = T::NR, PA = T::PA, W = T::W, RS = T::RS, NCH = T::NCH, CQ = T::CQ;
+    constexpr int S = 2 * SH;
+
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    const int q0 = blockIdx.x * NT;
+    const int m0 = blockIdx.y * MT + wm * (MT / T::WM);
+    const int b = blockIdx.z;
+    const int L = a.L;
+    const float slope = a.slope_in;
+    const float* __restrict__ xb = a.x + (long)b * a.x_sb;
+
+    const float4* __restrict__ wbase[MR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) wbase[mr] = reinterpret_cast<const float4*>(a.wp) + (long)(m0 / 32 + mr) * (NCH * CQ * 4) * 64 + lane;
+
+    f32x16 acc[2][MR][NR];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][mr][nr][r] = 0.0f;
+
+    const int colbase = wn * (NT / WN) + l31 + PA;  // frame q;  -1 / +1 for the neighbours
+
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        if (chunk) __syncthreads();
+        {
+            constexpr int W4 = W / 4;
+            const float* __restrict__ xc = xb + (long)(chunk * CK) * a.x_sc;
+            for (int idx = tid; idx < CK * W4; idx += 256) {
+                const int row = idx / W4;
+                const int c4 = idx - row * W4;
+                const int t = q0 - PA + 4 * c4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + t);
+                v.x = lrelu(v.x, slope);
+                v.y = lrelu(v.y, slope);
+                v.z = lrelu(v.z, slope);
+                v.w = lrelu(v.w, slope);
+                *reinterpret_cast<float4*>(&xs[row * RS + 4 * c4]) = v;
+            }
+        }
+        __syncthreads();
+
+        for (int cq = 0; cq < CQ; ++cq) {
+            float4 aw[MR][4];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int gm = 0; gm < 4; ++gm) aw[mr][gm] = wbase[mr][((long)(chunk * CQ + cq) * 4 + gm) * 64];
+            const float* xrow = &xs[(cq * 8 + lh) * RS + colbase];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bm[NR], bz[NR], bp[NR];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const float* p = xrow + e * 2 * RS + nr * 32;
+                    bm[nr] = p[-1];
+                    bz[nr] = p[0];
+                    bp[nr] = p[1];
+                }
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    float av[4];
+#pragma unroll
+                    for (int gm = 0; gm < 4; ++gm)
+                        av[gm] = e == 0 ? aw[mr][gm].x : e == 1 ? aw[mr][gm].y : e == 2 ? aw[mr][gm].z : aw[mr][gm].w;
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        acc[0][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bm[nr], acc[0][mr][nr], 0, 0, 0);
+                        acc[1][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bz[nr], acc[1][mr][nr], 0, 0, 0);
+                        acc[0][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bz[nr], acc[0][mr][nr], 0, 0, 0);
+                        acc[1][mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bp[nr], acc[1][mr][nr], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane owns S consecutive samples y[co][S*q .. S*q + S-1] per (co) it holds ----
+    const long Lout = (long)L * S;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int q = q0 + wn * (NT / WN) + nr * 32 + l31;
+            if (q < L) {
+                if constexpr (SH == 4) {
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int co = (m0 + mr * 32 + 8 * rq + 4 * lh) / 4;
+                        const float bv = a.bias[co];
+                        float* yp = a.y + ((long)b * COUT + co) * Lout + (long)q * S;
+                        float4 v0, v1;
+                        v0.x = acc[0][mr][nr][4 * rq + 0] + bv;
+                        v0.y = acc[0][mr][nr][4 * rq + 1] + bv;
+                        v0.z = acc[0][mr][nr][4 * rq + 2] + bv;
+                        v0.w = acc[0][mr][nr][4 * rq + 3] + bv;
+                        v1.x = acc[1][mr][nr][4 * rq + 0] + bv;
+                        v1.y = acc[1][mr][nr][4 * rq + 1] + bv;
+                        v1.z = acc[1][mr][nr][4 * rq + 2] + bv;
+                        v1.w = acc[1][mr][nr][4 * rq + 3] + bv;
+                        *reinterpret_cast<float4*>(yp) = v0;
+                        *reinterpret_cast<float4*>(yp + 4) = v1;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float bv = a.bias[co];
+                        float2 v;
+                        v.x = acc[0][mr][nr][r] + bv;
+                        v.y = acc[1][mr][nr][r] + bv;
+                        *reinterpret_cast<float2*>(a.y + ((long)b * COUT + co) * Lout + (long)q * 2) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+//                        CIN  COUT SH  MT   NT  WM WN CK
+using TileUp0 = ConvTTile<512, 256, 4, 128, 64, 2, 2, 64>;
+using TileUp1 = ConvTTile<256, 128, 4, 128, 64, 2, 2, 64>;
+using TileUp2 = ConvTTile<128, 64, 1, 64, 128, 2, 2, 64>;
+using TileUp3 = ConvTTile<64, 32, 1, 32, 256, 1, 4, 64>;
+
+static int convT_tile_id(int Cin, int Cout, int K, int stride) {
+    if (Cin == 512 && Cout == 256 && K == 16 && stride == 8) return 0;
+    if (Cin == 256 && Cout == 128 && K == 16 && stride == 8) return 1;
+    if (Cin == 128 && Cout == 64 && K == 4 && stride == 2) return 2;
+    if (Cin == 64 && Cout == 32 && K == 4 && stride == 2) return 3;
+    return -1;
+}
+
+// tap index for (group g, tap m, phase-in-group ph), or -1 if the polyphase split is not the
+// "(q-1,q) / (q,q+1)" one this kernel implements
+static int convT_tap(int K, int s, int pad_a, int g, int m, int ph) {
+    const int r = g * (s / 2) + ph;
+    const int j = s * (g - 1 + m) + pad_a - r;
+    return (j >= 0 && j < K) ? j : -1;
+}
+
+bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L) {
+    if (convT_tile_id(Cin, Cout, K, stride) < 0) return false;
+    if (K != 2 * stride || L % 4 != 0) return false;
+    // every phase must own exactly taps {j(g,0), j(g,1)} — verify against the definition
+    for (int r = 0; r < stride; ++r) {
+        int j0 = ((pad_a - r) % stride + stride) % stride;
+        const int g = r / (stride / 2), ph = r % (stride / 2);
+        int cnt = 0;
+        for (int j = j0; j < K; j += stride, ++cnt) {
+            const int off = (r + j - pad_a) / stride;
+            if (cnt > 1 || off != g - 1 + cnt || convT_tap(K, stride, pad_a, g, cnt, ph) != j) return false;
+        }
+        if (cnt != 2) return false;
+    }
+    return true;
+}
+
+size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K) { return (size_t)Cin * Cout * K; }
+
+void convT1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, float* out) {
+    const int SH = stride / 2, MP = Cout * SH, CK = 64, NCH = Cin / CK, CQ = CK / 8;
+    size_t o = 0;
+    for (int mblk = 0; mblk < MP / 32; ++mblk)
+        for (int chunk = 0; chunk < NCH; ++chunk)
+            for (int cq = 0; cq < CQ; ++cq)
+                for (int gm = 0; gm < 4; ++gm)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int mp = mblk * 32 + (lane & 31);
+                            const int co = mp / SH, ph = mp % SH;
+                            const int ci = chunk * CK + 2 * (4 * cq + e) + (lane >> 5);
+                            const int j = convT_tap(K, stride, pad_a, gm >> 1, gm & 1, ph);
+                            out[o++] = w_hk[((size_t)j * Cout + co) * Cin + ci];  // Haiku [K][Cout][Cin]
+                        }
+}
+
+template <class T>
+static hipError_t launch_ttile(const ConvArgs& a, hipStream_t s) {
+    dim3 grid((a.L + T::NT - 1) / T::NT, T::MP / T::MT, a.B);
+    hipLaunchKernelGGL(convT1d_f32_mfma_k<T>, grid, dim3(256), T::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_convT1d_f32_mfma(const ConvArgs& a, hipStream_t s) {
+    switch (convT_tile_id(a.Cin, a.Cout, a.K, a.stride)) {
+        case 0: return launch_ttile<TileUp0>(a, s);
+        case 1: return launch_ttile<TileUp1>(a, s);
+        case 2: return launch_ttile<TileUp2>(a, s);
+        case 3: return launch_ttile<TileUp3>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// =================================================================================================
+// conv_post: LeakyReLU(0.01) -> Conv1d 32 -> 1, k = 7 -> tanh   (model.py:122-124)
+// =================================================================================================
+// Not GEMM-shaped (one output channel): a streaming reduction over the largest activation of the
+// network.  Each thread produces 4 consecutive samples from three aligned float4 loads per input
+// channel; weights (C*7 floats) sit in LDS.  HBM-bound: 4*C bytes read + 4 written per sample.
+template <int C, int KS>
+__global__ __launch_bounds__(256) void conv_post_k(ConvArgs a) {
+    static_assert(KS == 7, "halo of 3 fits the [t-4, t+8) window");
+    __shared__ float ws[KS * C];
+    for (int i = threadIdx.x; i < KS * C; i += 256) ws[i] = a.w[i];  // Haiku [K][Cin][1]
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long L = a.L;
+    const float* __restrict__ xb = a.x + (long)b * a.x_sb;
+    const float slope = a.slope_in;
+    const float bias = a.bias[0];
+    for (long t = ((long)blockIdx.x * 256 + threadIdx.x) * 4; t < L; t += (long)gridDim.x * 1024) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int ci = 0; ci < C; ++ci) {
+            const float* xr = xb + (long)ci * a.x_sc + t;
+            float v[12];
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 lo = (t >= 4) ? *reinterpret_cast<const float4*>(xr - 4) : z;
+            const float4 mid = *reinterpret_cast<const float4*>(xr);
+            const float4 hi = (t + 4 < L) ? *reinterpret_cast<const float4*>(xr + 4) : z;
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+            v[4] = mid.x; v[5] = mid.y; v[6] = mid.z; v[7] = mid.w;
+            v[8] = hi.x; v[9] = hi.y; v[10] = hi.z; v[11] = hi.w;
+#pragma unroll
+            for (int i = 1; i < 11; ++i) v[i] = lrelu(v[i], slope);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const float wv = ws[j * C + ci];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wv, v[o + j + 1], acc[o]);  // x[t + o + j - 3]
+            }
+        }
+        float4 pre, out;
+        pre.x = acc[0] + bias; pre.y = acc[1] + bias; pre.z = acc[2] + bias; pre.w = acc[3] + bias;
+        out.x = tanhf(pre.x); out.y = tanhf(pre.y); out.z = tanhf(pre.z); out.w = tanhf(pre.w);
+        const long idx = (long)b * L + t;
+        if (a.pre_act) *reinterpret_cast<float4*>(a.pre_act + idx) = pre;
+        *reinterpret_cast<float4*>(a.y + idx) = out;
+    }
+}
+
+bool conv_post_fast_supported(int Cin, int Cout, int K, int L) { return Cin == 32 && Cout == 1 && K == 7 && L % 4 == 0; }
+
+hipError_t launch_conv_post_fast(const ConvArgs& a, hipStream_t s) {
+    long nthr = ((long)a.L / 4 + 255) / 256;
+    int gx = (int)(nthr < 4096 ? nthr : 4096);
+    hipLaunchKernelGGL((conv_post_k<32, 7>), dim3(gx, a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 }  // namespace vtts

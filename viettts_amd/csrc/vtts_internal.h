@@ -34,18 +34,20 @@ struct ConvArgs {
     float div;           // divisor for ACC_MEAN
     int tanh_out;        // apply tanh to the result (conv_post)
     float* pre_act;      // optional copy of the pre-tanh value (same indexing as y) or nullptr
+    int tile_pref;       // MFMA time-tile choice: 0 = by problem size, 1 = wide, 2 = narrow (tests)
 };
 
 // ---- generic (any shape) fp32 kernels: kernels_generic.hip -------------------------------
 hipError_t launch_conv1d_generic(const ConvArgs& a, hipStream_t s);
 hipError_t launch_convT1d_generic(const ConvArgs& a, hipStream_t s);
 
-// ---- fp32 MFMA implicit-GEMM convolution (Cin == Cout in {32,64,128,256}, K in {3,7,11}) --
-// Returns false in *supported if the shape has no MFMA instantiation.
-bool conv1d_f32_mfma_supported(int C, int K, int dil, int L);
-size_t conv1d_f32_mfma_packed_floats(int C, int K);
-// host-side re-layout: Haiku [K][Cin][Cout] -> MFMA A-fragment order (see kernels_f32_mfma.hip)
-void conv1d_f32_mfma_pack(const float* w_hk, int C, int K, float* out);
+// ---- fp32 MFMA implicit-GEMM convolution: kernels_f32_mfma.hip ------------------------------
+// ResBlock shapes (Cin == Cout in {32,64,128,256}, K in {3,7,11}, channel-major input) and conv_pre
+// (80 -> 512, K = 7, time-major input: nwc = true).
+bool conv1d_f32_mfma_supported(int Cin, int Cout, int K, int dil, int L, bool nwc);
+size_t conv1d_f32_mfma_packed_floats(int Cin, int Cout, int K);
+// host-side re-layout: Haiku [K][Cin][Cout] -> MFMA A-fragment order
+void conv1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, float* out);
 hipError_t launch_conv1d_f32_mfma(const ConvArgs& a, hipStream_t s);
 const char* conv1d_f32_mfma_kernel_name(int C, int K);
 
@@ -54,5 +56,9 @@ bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a,
 size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K);
 void convT1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, float* out);
 hipError_t launch_convT1d_f32_mfma(const ConvArgs& a, hipStream_t s);
+
+// ---- streaming conv_post (32 -> 1, K = 7, fused LeakyReLU + tanh) ----------------------------
+bool conv_post_fast_supported(int Cin, int Cout, int K, int L);
+hipError_t launch_conv_post_fast(const ConvArgs& a, hipStream_t s);
 
 }  // namespace vtts
