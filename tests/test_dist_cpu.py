@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: pure partitioning functions, and a world_size-2 gloo run of the one collective
+the design has (the start-up weight broadcast) plus the optional end-of-job gather."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from viettts_amd.dist import (HALO_FRAMES, broadcast_packed_weights, gather_to_rank0, plan_chunks, shard_chunks,
+                              shard_utterances)
+
+
+def test_shard_utterances_partition_and_balance():
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(50, 2000, size=257).tolist()
+    for world in (1, 2, 4, 8):
+        shards = shard_utterances(lengths, world)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(len(lengths)))  # every utterance exactly once
+        loads = [sum(lengths[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lengths)  # greedy LPT bound
+        assert shards == shard_utterances(lengths, world)  # deterministic: every rank computes the same plan
+    assert shard_utterances([], 4) == [[], [], [], []]
+    with pytest.raises(ValueError):
+        shard_utterances([1, 2], 0)
+
+
+@pytest.mark.parametrize("T,chunk", [(1, 512), (512, 512), (513, 512), (4096, 512), (37500, 512), (100, 7)])
+def test_plan_chunks_cover_exactly(T, chunk):
+    chunks = plan_chunks(T, chunk)
+    assert chunks[0].t0 == 0 and chunks[-1].t1 == T
+    for a, b in zip(chunks, chunks[1:]):
+        assert a.t1 == b.t0  # kept ranges tile [0, T) with no gap / overlap
+    for c in chunks:
+        assert 0 <= c.lo <= c.t0 < c.t1 <= c.hi <= T
+        assert c.t0 - c.lo == min(HALO_FRAMES, c.t0)  # full halo inside, none at the true edge
+        assert c.hi - c.t1 == min(HALO_FRAMES, T - c.t1)
+        assert c.keep_from == c.t0 - c.lo
+    for world in (1, 2, 8):
+        sh = shard_chunks(chunks, world)
+        assert sorted(c.index for s in sh for c in s) == [c.index for c in chunks]
+        for r, s in enumerate(sh):
+            assert all(c.index % world == r for c in s)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from viettts_amd import dist as vdist
+
+    info = vdist.init_process_group("gloo")
+    assert (info.rank, info.world) == (rank, world)
+    # rank 0 "packs" the weights; every other rank allocates an empty blob of the same size and receives it
+    n = 1 << 16
+    ref = (torch.arange(n, dtype=torch.int64) * 2654435761 % 251).to(torch.uint8)
+    blob = ref.clone() if rank == 0 else torch.zeros(n, dtype=torch.uint8)
+    broadcast_packed_weights(blob, 0)
+    ok_bcast = bool(torch.equal(blob, ref))
+    # independent shards, no collective on the data path: each rank "synthesises" its own utterances
+    lengths = [5, 9, 3, 7, 2]
+    mine = shard_utterances(lengths, world)[rank]
+    local = torch.cat([torch.full((lengths[i],), float(i)) for i in mine]) if mine else torch.zeros(0)
+    got = gather_to_rank0(local, info)
+    if rank == 0:
+        plan = shard_utterances(lengths, world)
+        ok_gather = all(torch.equal(got[r], torch.cat([torch.full((lengths[i],), float(i)) for i in plan[r]])) for r in range(world))
+    else:
+        ok_gather = got is None
+    q.put((rank, ok_bcast, ok_gather))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_and_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, True), (1, True, True)]

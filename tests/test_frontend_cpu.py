@@ -1,0 +1,75 @@
+"""Host logic around the path: text front end, integer frame counts, WAV writer, CLI parser."""
+import numpy as np
+import pytest
+
+from viettts_amd.nat import text2mel as t2m
+from viettts_amd.nat.config import FLAGS, load_phonemes_set
+from viettts_amd.synthesizer import build_parser, nat_normalize_text
+from viettts_amd.wavio import float_to_pcm16, read_wav, write_wav
+
+
+def test_phoneme_inventory():
+    ph = load_phonemes_set()
+    assert ph[:4] == ["sil", "sp", "spn", " "] and len(ph) == 4 + 89  # vietTTS/nat/config.py:24-39
+    assert len(set(ph)) == len(ph)
+    assert ph[4] == "a" and ph[-1] == "ỹ" and ph.index("đ") == 4 + 39
+
+
+def test_normalize_text_matches_reference_rules():
+    # vietTTS/synthesizer.py:21-31 — expected strings derived by hand from those six substitutions
+    assert nat_normalize_text("Xin chào, thế giới.") == "xin chào sil thế giới sil"
+    assert nat_normalize_text('  "A"\nB:  c!?') == "a sil b sil c sil"
+    assert nat_normalize_text("a . , : b") == "a sil b"
+
+
+def test_text2tokens(tmp_path):
+    lex = tmp_path / "lexicon.txt"
+    lex.write_text("xin\t x i n\nchào\t c h à o\n", encoding="utf-8")
+    ph = load_phonemes_set()
+    toks = t2m.text2tokens("xin sil chào zzq", lex)
+    want = [0] + [ph.index(c) for c in "xin"] + [3] + [0] + [ph.index(c) for c in "chào"] + [3] + [ph.index("q"), 3] + [0]
+    assert toks == want  # 'z' is not a phoneme: dropped letter-wise (text2mel.py:52-56)
+
+
+def test_integer_frame_counts_are_fp32_truncations():
+    d = np.array([[0.2, 0.0317, 0.1234567, 0.5]], dtype=np.float32)
+    frames = t2m.durations_to_frames(d)
+    assert frames.dtype == np.float32
+    assert np.array_equal(frames, (d * np.float32(16000)) / np.float32(256))
+    assert t2m.n_frames_from_durations(d) == int(np.float32(np.sum(frames, dtype=np.float32)))
+    assert t2m.n_frames_from_durations(np.array([[1.0, 1.0]], np.float32)) == 125
+    assert t2m.trailing_silence_frames(np.array([[0.1, 0.2]], np.float32)) == int(float(np.float32(0.2)) * 16000 / 256)
+    r = t2m.apply_duration_rules([0, 5, 3, 0], np.array([[0.01, 0.1, 0.3, 0.02]], np.float32), 0.2)
+    assert np.allclose(r, [[0.2, 0.1, 0.0, 0.2]])
+    r = t2m.apply_duration_rules([0, 5, 3, 0], np.array([[0.01, 0.1, 0.3, 0.02]], np.float32), -1.0)
+    assert np.allclose(r, [[0.01, 0.1, 0.0, 0.02]])
+
+
+def test_text2mel_surface(tmp_path):
+    lex = tmp_path / "lexicon.txt"
+    lex.write_text("a\t a\n", encoding="utf-8")
+    t2m.set_mel_provider(None)
+    with pytest.raises(NotImplementedError):
+        t2m.text2mel("a", lex)
+    t2m.set_mel_provider(lambda tokens, lf, sd: np.zeros((1, len(tokens), 80), np.float32))
+    try:
+        mel = t2m.text2mel("a a", lex, silence_duration=0.2)
+        assert mel.shape == (1, 6, 80) and mel.dtype == np.float32
+    finally:
+        t2m.set_mel_provider(None)
+
+
+def test_wav_writer_roundtrip(tmp_path):
+    x = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 1.7, 1e-5], dtype=np.float32)
+    assert float_to_pcm16(x).tolist() == [0, 16384, -16384, 32767, -32767, 32767, 0]
+    write_wav(tmp_path / "a.wav", x, 16000)
+    sr, pcm = read_wav(tmp_path / "a.wav")
+    assert sr == 16000 and pcm.tolist() == float_to_pcm16(x).tolist()
+    assert (tmp_path / "a.wav").stat().st_size == 44 + 2 * len(x)
+
+
+def test_cli_flags_match_reference():
+    a = build_parser().parse_args([])
+    assert str(a.output) == "clip.wav" and a.sample_rate == 16000 and a.silence_duration == -1 and a.lexicon_file is None
+    a = build_parser().parse_args(["--text", "x", "--output", "o.wav", "--sample-rate", "22050", "--silence-duration", "0.2", "--lexicon-file", "l.txt"])
+    assert a.text == "x" and a.sample_rate == 22050 and a.silence_duration == 0.2 and a.lexicon_file == "l.txt"

@@ -1,0 +1,82 @@
+"""Chunked long-form synthesis and the CLI on the GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from viettts_amd.hifigan.config import V1
+from viettts_amd.hifigan.synth import synthetic_mel, synthetic_params
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gen():
+    from viettts_amd.hifigan.generator import Generator
+
+    g = Generator(V1, device="cuda:0")
+    g.load_params(synthetic_params(V1, 4321, "scaled"))
+    yield g
+    g.close()
+
+
+def test_chunked_equals_unchunked(gen):
+    """BASELINE configs[4] acceptance: chunked == un-chunked on a shorter clip (here 1500 frames,
+    chunks of 256 + 13-frame halos, ragged last chunk)."""
+    from viettts_amd.longform import synthesize_chunked
+
+    mel = torch.from_numpy(synthetic_mel(1, 1500, 3)).to("cuda:0")
+    full = gen(mel)[0]
+    timing = {}
+    got = synthesize_chunked(gen, mel[0], chunk_frames=256, max_batch=4, timing=timing)
+    assert got.shape == full.shape
+    assert (got - full).abs().max().item() < 5e-6
+    assert timing["chunks"] == 6 and 0 < timing["first_chunk_s"] <= timing["total_s"]
+    # chunk-DP: two "ranks" computed separately cover the clip disjointly and add up to the same thing
+    a = synthesize_chunked(gen, mel[0], chunk_frames=256, rank=0, world=2)
+    b = synthesize_chunked(gen, mel[0], chunk_frames=256, rank=1, world=2)
+    assert ((a != 0) & (b != 0)).sum().item() == 0
+    assert (a + b - full).abs().max().item() < 5e-6
+
+
+def test_dp_setup_single_rank(gen):
+    from viettts_amd import dist as vdist
+    from viettts_amd.hifigan.generator import Generator
+
+    g2 = Generator(V1, device="cuda:0")
+    # a second rank would receive rank 0's packed blob over RCCL; adopting it must give identical output
+    g2.adopt_packed(gen.packed_blob().clone())
+    mel = torch.from_numpy(synthetic_mel(2, 20, 9)).to("cuda:0")
+    assert torch.equal(g2(mel), gen(mel))
+    g2.close()
+    g3 = Generator(V1, device="cuda:0")
+    vdist.setup_generator_dp(g3, lambda: synthetic_params(V1, 4321, "scaled"), vdist.RankInfo(0, 1, 0))
+    assert torch.equal(g3(mel), gen(mel))
+    g3.close()
+
+
+def test_cli_mel_file(tmp_path):
+    from viettts_amd.hifigan.weights import save_haiku_pickle
+    from viettts_amd.wavio import float_to_pcm16, read_wav
+    from oracle.hifigan_oracle import mel2wave_oracle
+
+    params = synthetic_params(V1, 4321, "scaled")
+    (tmp_path / "assets/hifigan").mkdir(parents=True)
+    (tmp_path / "assets/infore/hifigan").mkdir(parents=True)
+    (tmp_path / "assets/hifigan/config.json").write_text(open(os.path.join(REPO, "assets/hifigan/config.json")).read())
+    save_haiku_pickle(tmp_path / "assets/infore/hifigan/hk_hifi.pickle", params)
+    mel = synthetic_mel(1, 12, 4)
+    np.save(tmp_path / "m.npy", mel[0])
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "viettts_amd.synthesizer", "--mel-file", "m.npy", "--output", "o.wav", "--sample-rate", "16000"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "writing output to file o.wav" in r.stdout
+    sr, pcm = read_wav(tmp_path / "o.wav")
+    want = float_to_pcm16(mel2wave_oracle(params, mel, V1))
+    assert sr == 16000 and len(pcm) == 12 * 256
+    assert np.abs(pcm.astype(np.int32) - want.astype(np.int32)).max() <= 1

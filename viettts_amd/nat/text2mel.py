@@ -1,0 +1,111 @@
+"""Call surface of ``vietTTS.nat.text2mel`` (vietTTS/nat/text2mel.py).
+
+What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
+  * ``load_lexicon`` / ``text2tokens`` — the deterministic text -> token-id front end (:16-19, :37-58);
+  * the two INTEGER quantities BASELINE.json wants bit-exact — ``n_frames`` (:78-79) and the trailing
+    ``silence_frame`` (:99-101) — as pure functions of the fp32 duration vector, computed with the
+    same dtype and operation order (fp32 multiply by 16000, fp32 divide by 256, fp32 sum, truncate);
+  * ``text2mel(text, lexicon_fn, silence_duration)`` with the reference's signature.
+
+What is NOT built yet: the NAT duration and acoustic networks themselves (vietTTS/nat/model.py —
+BiLSTM encoder, autoregressive 2xLSTM decoder with always-on prenet dropout driven by JAX's threefry
+PRNG).  They are "next" rows, upstream of the hot path; ``text2mel`` therefore raises
+``NotImplementedError`` unless a mel provider has been registered with :func:`set_mel_provider`
+(tests and the CLI's ``--mel-file`` use that hook).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .config import FLAGS, load_phonemes_set
+
+FRAMES_PER_SECOND_NUM = FLAGS.sample_rate  # durations * sample_rate / (n_fft // 4), text2mel.py:78
+FRAMES_PER_SECOND_DEN = FLAGS.n_fft // 4
+
+
+def load_lexicon(fn) -> Dict[str, str]:
+    """word<TAB>phonemes per line, lower-cased (text2mel.py:16-19)."""
+    out: Dict[str, str] = {}
+    with open(fn, "r", encoding="utf-8") as f:
+        for line in f:
+            parts = line.lower().strip().split("\t")
+            if len(parts) == 2:
+                out[parts[0]] = parts[1]
+            elif len(parts) > 2:  # the reference's dict(lines) would raise; keep first two fields
+                out[parts[0]] = parts[1]
+    return out
+
+
+def text2tokens(text: str, lexicon_fn) -> List[int]:
+    """sil + per word (special phoneme | lexicon phonemes + word_end | known letters + word_end) + sil
+    (text2mel.py:37-58)."""
+    phonemes = load_phonemes_set()
+    index = {p: i for i, p in enumerate(phonemes)}
+    lexicon = load_lexicon(lexicon_fn)
+    tokens = [FLAGS.sil_index]
+    for word in text.strip().lower().split():
+        if word in FLAGS.special_phonemes:
+            tokens.append(index[word])
+        elif word in lexicon:
+            tokens.extend(index[p] for p in lexicon[word].split())
+            tokens.append(FLAGS.word_end_index)
+        else:
+            tokens.extend(index[ch] for ch in word if ch in index)
+            tokens.append(FLAGS.word_end_index)
+    tokens.append(FLAGS.sil_index)
+    return tokens
+
+
+def apply_duration_rules(tokens: Sequence[int], durations: np.ndarray, silence_duration: float) -> np.ndarray:
+    """sil tokens: clip(duration, min=silence_duration); word-end tokens: 0 (text2mel.py:90-97).
+    ``durations`` is float32 ``[1, L]`` in seconds."""
+    d = np.asarray(durations, dtype=np.float32).copy()
+    tok = np.asarray(tokens)[None, :]
+    d = np.where(tok == FLAGS.sil_index, np.maximum(d, np.float32(silence_duration)), d).astype(np.float32)
+    d = np.where(tok == FLAGS.word_end_index, np.float32(0.0), d).astype(np.float32)
+    return d
+
+
+def durations_to_frames(durations: np.ndarray) -> np.ndarray:
+    """seconds -> frames in fp32 with the reference's operation order:
+    ``durations * sample_rate / (n_fft // 4)`` (text2mel.py:78) = (d * 16000f) / 256f."""
+    d = np.asarray(durations, dtype=np.float32)
+    return (d * np.float32(FRAMES_PER_SECOND_NUM)) / np.float32(FRAMES_PER_SECOND_DEN)
+
+
+def n_frames_from_durations(durations: np.ndarray) -> int:
+    """``int(jnp.sum(durations_in_frames).item())`` (text2mel.py:79): fp32 sum, truncation."""
+    return int(np.sum(durations_to_frames(durations), dtype=np.float32))
+
+
+def trailing_silence_frames(durations: np.ndarray) -> int:
+    """``int(end_silence * sample_rate / (n_fft // 4))`` with ``end_silence`` a Python float
+    (text2mel.py:99-101): the fp32 duration is widened to double by ``.item()`` first."""
+    end_silence = float(np.asarray(durations, dtype=np.float32)[0, -1])
+    return int(end_silence * FLAGS.sample_rate / (FLAGS.n_fft // 4))
+
+
+_MEL_PROVIDER: Optional[Callable] = None
+
+
+def set_mel_provider(fn: Optional[Callable]) -> None:
+    """Register ``fn(tokens, lexicon_fn, silence_duration) -> mel [1, T, 80]`` standing in for the NAT
+    networks until those rows are built."""
+    global _MEL_PROVIDER
+    _MEL_PROVIDER = fn
+
+
+def text2mel(text: str, lexicon_fn=FLAGS.data_dir / "lexicon.txt", silence_duration: float = -1.0):
+    """Reference signature (text2mel.py:85-87).  Returns ``[1, T, 80]`` float32 log-mel."""
+    tokens = text2tokens(text, lexicon_fn)
+    if _MEL_PROVIDER is None:
+        raise NotImplementedError(
+            "the NAT duration/acoustic networks are not built yet (SURVEY.md §8f ranks 2-3); "
+            "register a mel provider with viettts_amd.nat.text2mel.set_mel_provider() or use the CLI's --mel-file"
+        )
+    mel = np.asarray(_MEL_PROVIDER(tokens, lexicon_fn, silence_duration), dtype=np.float32)
+    if mel.ndim != 3 or mel.shape[0] != 1 or mel.shape[2] != FLAGS.mel_dim:
+        raise ValueError(f"mel provider returned shape {mel.shape}, expected [1, T, {FLAGS.mel_dim}]")
+    return mel
