@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=1024, help="mel frames per utterance")
-    ap.add_argument("--dtype", default="f32", choices=["f32"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
@@ -92,9 +92,9 @@ def main():
     dev = torch.device("cuda", info.local_rank)
 
     gen = Generator(V1, device=dev, dtype=args.dtype)
-    vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info)
     if args.microbatch:
         gen.set_option("microbatch", args.microbatch)
+    vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info)
 
     B, T = args.batch, args.frames
     # per-rank shard of the global batch: distinct seeded mels, resident in HBM before timing

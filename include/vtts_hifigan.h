@@ -120,6 +120,9 @@ int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, fl
  * forward() that also copies one intermediate out, for parity tests.  `tap` names follow the
  * oracle: "conv_pre", "ups_<i>", "mrf_<i>" (each [B, C, L] fp32, channel-major) and
  * "pre_tanh" ([B, hop*T]).  tap_dev must hold vtts_hifigan_tap_elems() floats.
+ * A VTTS_BF16 handle returns taps channels-last ([B, L, C], converted to fp32), and "conv_pre" /
+ * "mrf_<i>" hold the tensor as stored, i.e. already through the consumer's LeakyReLU (0.1; 0.01 for
+ * the last stage).
  */
 int vtts_hifigan_tap_elems(const vtts_hifigan* h, const char* tap, int B, int T, size_t* elems);
 int vtts_hifigan_forward_tap(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev,
@@ -133,6 +136,8 @@ int vtts_hifigan_forward_tap(vtts_hifigan* h, const float* mel_dev, int B, int T
  *   slope_in : LeakyReLU slope applied to the input on load (1.0 = none)
  *   res_dev  : optional residual added to the output (may alias y_dev), or NULL
  * The output length is L for convolutions and stride*L for ups_*.
+ * For a VTTS_BF16 handle the arrays are fp32 but CHANNELS-LAST ([B, L, C], the bf16 path's internal
+ * layout), are rounded to bf16 on the way in, and the call synchronises the stream.
  */
 int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev, int B, int L,
                             float slope_in, const float* res_dev, float* y_dev, vtts_stream stream);

@@ -1,0 +1,155 @@
+"""bf16 path (BASELINE configs[2]) on the GPU.  BASELINE.json fixes a tolerance only for fp32 (1e-4);
+for bf16 the tests (a) check every kernel against the oracle evaluated on the SAME bf16-rounded
+operands — so that only fp32-accumulation order and the final bf16 rounding differ — and (b) report
+and bound the end-to-end error against the fp64 golden vectors of the reference."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hifigan_oracle as orc
+from viettts_amd.hifigan.config import TINY, V1
+from viettts_amd.hifigan.synth import synthetic_mel, synthetic_params
+from viettts_amd.hifigan.weights import conv_specs
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    """round-to-nearest-even to bf16, returned as float64"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def v1_params():
+    return synthetic_params(V1, 4321, "scaled")
+
+
+@pytest.fixture(scope="module")
+def gen(dev, v1_params):
+    from viettts_amd.hifigan.generator import Generator
+
+    g = Generator(V1, device=dev, dtype="bf16")
+    g.load_params(v1_params)
+    yield g
+    g.close()
+
+
+def _rel(got, ref):
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def _res_conv_cases():
+    seen, out = set(), []
+    for s in conv_specs(V1):
+        if s.kind == "conv" and s.cin == s.cout:
+            sig = (s.cin, s.k, s.dilation)
+            if sig not in seen:
+                seen.add(sig)
+                out.append(s)
+    return out
+
+
+@pytest.mark.parametrize("spec", _res_conv_cases(), ids=lambda s: f"C{s.cin}k{s.k}d{s.dilation}")
+def test_resblock_conv_kat_bf16(gen, v1_params, dev, spec):
+    rng = np.random.default_rng(spec.cin * 1000 + spec.k * 10 + spec.dilation)
+    B, L = 2, 700  # ragged: not a multiple of the 256/512 time tiles
+    x = rng.standard_normal((B, L, spec.cin)).astype(np.float32) * 2.0
+    res = rng.standard_normal((B, L, spec.cin)).astype(np.float32)
+    w, b = v1_params[spec.key]["w"], v1_params[spec.key]["b"]
+    xin = bf(orc.leaky_relu(bf(x), 0.1))  # kernel: bf16(lrelu(bf16 x)) while staging
+    ref = orc.conv1d(xin, bf(w), b.astype(np.float64), spec.dilation, orc.get_padding(spec.k, spec.dilation)) + bf(res)
+    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 0.1, torch.from_numpy(res).to(dev)).cpu().numpy()
+    # only the output's bf16 rounding (2^-9 relative) and fp32 accumulation order differ
+    assert np.abs(y - ref).max() <= 2.0 ** -8 * np.abs(ref).max(), (np.abs(y - ref).max(), np.abs(ref).max())
+    assert np.abs(y - bf(ref)).max() <= 2.0 ** -7 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_upsample_kat_bf16(gen, v1_params, dev, i):
+    spec = [s for s in conv_specs(V1) if s.key == f"generator/~/ups_{i}"][0]
+    rng = np.random.default_rng(40 + i)
+    B, L = 2, 300
+    x = rng.standard_normal((B, L, spec.cin)).astype(np.float32) * 2.0
+    w, b = v1_params[spec.key]["w"], v1_params[spec.key]["b"]
+    ref = orc.conv1d_transpose(bf(x), bf(w), b.astype(np.float64), spec.stride)
+    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 1.0).cpu().numpy()
+    assert y.shape == (B, L * spec.stride, spec.cout)
+    assert np.abs(y - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+
+
+def test_conv_pre_and_post_bf16(gen, v1_params, dev):
+    mel = synthetic_mel(2, 300, 5)
+    w, b = v1_params["generator/~/conv1_d"]["w"], v1_params["generator/~/conv1_d"]["b"]
+    ref = orc.conv1d(bf(mel), bf(w), b.astype(np.float64), 1, 3)
+    y = gen.run_module("generator/~/conv1_d", torch.from_numpy(mel).to(dev), 1.0).cpu().numpy()
+    assert np.abs(y - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 1000, 32)).astype(np.float32)
+    w, b = v1_params["generator/~/conv1_d_1"]["w"], v1_params["generator/~/conv1_d_1"]["b"]
+    ref = np.tanh(orc.conv1d(bf(x), w.astype(np.float64), b.astype(np.float64), 1, 3))[..., 0]  # fp32 weights
+    y = gen.run_module("generator/~/conv1_d_1", torch.from_numpy(x).to(dev), 1.0).cpu().numpy()
+    assert y.shape == (2, 1000)
+    assert np.abs(y - ref).max() < 1e-5
+
+
+def test_generator_bf16_vs_reference_golden(golden_dir, gen, dev, capsys):
+    """End-to-end error of the bf16 path against the reference's fp64 output (reported, loosely bounded)."""
+    meta = json.load(open(golden_dir / "golden_meta.json"))["cases"]
+    worst = {}
+    for case in ("v1_scaled_T8", "v1_scaled_T37"):
+        rec = meta[case]
+        g = np.load(golden_dir / f"{case}.npz")
+        mel = torch.from_numpy(synthetic_mel(rec["B"], rec["T"], rec["mseed"])).to(dev)
+        wav, pre = gen.forward_tap(mel, "pre_tanh")
+        torch.cuda.synchronize()
+        e_y = float(np.abs(wav.cpu().numpy() - g["y64"]).max())
+        e_p = float(np.abs(pre.cpu().numpy() - g["pre64"]).max())
+        snr = 10 * np.log10((g["pre64"] ** 2).mean() / ((pre.cpu().numpy() - g["pre64"]) ** 2).mean())
+        worst[case] = (e_y, e_p, float(snr))
+        assert e_y < 0.1 and e_p < 0.1 and snr > 25.0, worst
+    with capsys.disabled():
+        print("\n[bf16 end-to-end vs fp64 reference] (max|dy|, max|dpre|, SNR dB):", worst)
+
+
+def test_bf16_taps_vs_oracle(gen, v1_params, dev):
+    mel = synthetic_mel(2, 9, 11)
+    taps = []
+    orc.generator_forward(v1_params, mel, V1, np.float64, taps=taps)
+    taps = dict(taps)
+    for name, slope in (("conv_pre", 0.1), ("ups_0", 1.0), ("mrf_0", 0.1), ("ups_3", 1.0), ("mrf_3", 0.01)):
+        want = taps[name]  # NWC
+        if slope != 1.0:
+            want = orc.leaky_relu(want, slope)  # the bf16 path stores these already activated
+        _, got = gen.forward_tap(torch.from_numpy(mel).to(dev), name)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(want.shape)
+        assert _rel(got, want) < 0.05, (name, _rel(got, want))
+
+
+def test_bf16_batch_and_microbatch_invariance(gen, dev):
+    mel = torch.from_numpy(synthetic_mel(5, 64, 21)).to(dev)
+    base = gen(mel).clone()
+    for mb in (1, 2, 5):
+        gen.set_option("microbatch", mb)
+        assert torch.equal(gen(mel), base)
+    gen.set_option("microbatch", 0)
+    assert torch.equal(gen(mel[3:4]), base[3:4])
+    assert torch.isfinite(base).all() and base.abs().max().item() < 1.0
+
+
+def test_bf16_rejects_unsupported_architecture(dev):
+    from viettts_amd import _lib
+    from viettts_amd.hifigan.generator import Generator
+
+    with pytest.raises(_lib.VttsError):
+        Generator(TINY, device=dev, dtype="bf16")

@@ -57,6 +57,10 @@ struct Layer {
     size_t off_w = 0, off_b = 0, off_wp = 0;
     bool has_wp = false;
     size_t wp_floats = 0;
+    // bf16 path: kernel class, packed bf16 weights, bias expanded to the GEMM's row count
+    int bcls = BCLS_NONE;
+    size_t off_wb = 0, wb_bytes = 0;
+    int coutp = 0;  // GEMM rows: cout, or stride*cout for a transposed convolution run as Conv1d(k=3)
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -93,6 +97,68 @@ int conv_same_pad_a(int k, int s) {
     // lax.conv_transpose padding="SAME": pad_len = k + s - 2; pad_a = k-1 if s > k-1 else ceil(pad_len/2)
     const int pad_len = k + s - 2;
     return (s > k - 1) ? (k - 1) : (pad_len + 1) / 2;
+}
+
+int classify_bf16(const vtts_hifigan* h, const Layer& l, bool is_pre, bool is_post) {
+    if (is_post) return (l.cin == 32 && l.cout == 1 && l.k == 7) ? BCLS_NONE - 1 : BCLS_NONE;  // -2 = streaming conv_post
+    if (is_pre) return (l.cin <= 128 && l.cin % 8 == 0 && l.cout == 512 && l.k == 7) ? BCLS_PRE : BCLS_NONE;
+    if (l.kind == KIND_CONVT) {
+        if (!convT1d_f32_mfma_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, 4)) return BCLS_NONE;  // same polyphase condition
+        if (l.cin == 512) return BCLS_UP0;
+        if (l.cin == 256) return BCLS_UP1;
+        if (l.cin == 128) return BCLS_UP2;
+        return BCLS_UP3;
+    }
+    if (l.cin != l.cout || !(l.k == 3 || l.k == 7 || l.k == 11) || l.dil > 5) return BCLS_NONE;
+    switch (l.cin) {
+        case 256: return BCLS_RES256;
+        case 128: return BCLS_RES128;
+        case 64: return BCLS_RES64;
+        case 32: return BCLS_RES32;
+    }
+    return BCLS_NONE;
+}
+
+int build_layers_bf16(vtts_hifigan* h) {
+    size_t off = 0;
+    double best_flops = -1.0;
+    for (auto& l : h->layers) {
+        const bool is_pre = (&l == &h->layers[h->idx_pre]), is_post = (&l == &h->layers[h->idx_post]);
+        l.bcls = classify_bf16(h, l, is_pre, is_post);
+        if (l.bcls == BCLS_NONE)
+            return fail(VTTS_ERR_INVALID, "dtype bf16: no kernel for module %s (%d->%d, k=%d): the bf16 path covers the HiFi-GAN V1 shapes",
+                        l.key.c_str(), l.cin, l.cout, l.k);
+        l.coutp = (l.kind == KIND_CONVT) ? l.cout * l.stride : l.cout;
+        l.off_b = off;
+        off = align_up(off + (size_t)l.coutp * sizeof(float), 256);
+        if (is_post) {
+            l.off_w = off;
+            off = align_up(off + (size_t)l.k * l.cin * l.cout * sizeof(float), 256);
+        } else {
+            const BPackGeom g = bf16_pack_geom(l.bcls, l.kind == KIND_CONVT ? 3 : l.k);
+            l.wb_bytes = bf16_packed_bytes(g);
+            l.off_wb = off;
+            off = align_up(off + l.wb_bytes, 256);
+            if (l.kind == KIND_CONV && l.cin == l.cout) {
+                double fl = 0.0;
+                long len2 = 1;
+                for (auto& m : h->layers) {
+                    if (m.kind == KIND_CONVT) len2 *= m.stride;
+                    if (m.kind == KIND_CONV && m.cin == l.cin && m.k == l.k && m.cin == m.cout) fl += 2.0 * len2 * m.cin * m.cout * m.k;
+                }
+                if (fl > best_flops) {
+                    best_flops = fl;
+                    h->prof_C = l.cin;
+                    h->prof_K = l.k;
+                }
+            }
+        }
+    }
+    h->blob_bytes = off;
+    char buf[96];
+    snprintf(buf, sizeof(buf), "conv_bf16_k<BTile<%d, %d, %d, %d", h->prof_C, h->prof_C > 128 ? 128 : h->prof_C, h->prof_C, h->prof_K);
+    h->prof_name = buf;
+    return VTTS_OK;
 }
 
 int build_layers(vtts_hifigan* h) {
@@ -135,6 +201,8 @@ int build_layers(vtts_hifigan* h) {
         }
     }
     h->idx_post = add("generator/~/conv1_d_1", KIND_CONV, c0 >> c.num_upsamples, 1, 7, 1, 1);
+
+    if (h->dtype == VTTS_BF16) return build_layers_bf16(h);
 
     // blob layout: per layer plain weights, bias, optional MFMA-packed weights; 256-B aligned
     size_t off = 0;
@@ -260,6 +328,55 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
     return VTTS_OK;
 }
 
+
+// ---- bf16 path -------------------------------------------------------------------------------------
+int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, int cin_real, int B, int L, float slope_in,
+                   float slope_out, const void* res, void* y, int acc_add, float div, hipStream_t s) {
+    BConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.wp = h->blob + l.off_wb;
+    a.bias = reinterpret_cast<const float*>(h->blob + l.off_b);
+    a.res = res;
+    a.y = y;
+    a.B = B;
+    a.L = L;
+    a.x_pitch = x_pitch;
+    a.cin_real = cin_real;
+    a.dil = (l.kind == KIND_CONVT) ? 1 : l.dil;
+    a.pad = (l.kind == KIND_CONVT) ? 1 : l.pad;
+    a.slope_in = slope_in;
+    a.slope_out = slope_out;
+    a.acc_add = acc_add;
+    a.div = div;
+    const int K = (l.kind == KIND_CONVT) ? 3 : l.k;
+    const bool prof = h->opt_profile && l.kind == KIND_CONV && l.cin == h->prof_C && l.cout == h->prof_C && l.k == h->prof_K;
+    if (prof) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            h->prof_events.emplace_back(e0, e1);
+        }
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+    }
+    hipError_t e = launch_conv_bf16(l.bcls, K, a, s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+        h->prof_used++;
+        h->prof_flops += 2.0 * (double)B * L * l.cin * l.cout * l.k;
+    }
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "bf16 kernel launch for %s failed: %s", l.key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
+struct Taps;
+int tap_copy_bf16(const void* src, float* dst, size_t n, hipStream_t s) {
+    hipError_t e = launch_bf16_to_f32(src, dst, n, s);
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "tap conversion failed: %s", hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 size_t max_act_elems(const vtts_hifigan* h, int T) {
     // largest [C][L] activation per utterance over all stages (8192*T for V1)
     size_t best = (size_t)h->cfg.upsample_initial_channel * T;
@@ -288,6 +405,89 @@ struct Taps {
     int Bfull = 0;
 };
 
+
+// bf16 schedule.  Same dataflow as the fp32 one, with two differences that only bf16 needs:
+//  * activations are channels-last bf16 [B][L][C] (a transposed convolution's [L][s*Cout] output IS the
+//    [s*L][Cout] tensor);
+//  * a tensor that is only ever consumed through LeakyReLU is stored already activated by its producer
+//    (in fp32, before the bf16 rounding): conv_pre -> ups_0, xt = c1(.) -> c2, MRF mean -> next ups / conv_post.
+//    Only the ResBlock's running x is stored raw (it is also the residual) and activated on load by c1.
+int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, hipStream_t s, Taps tap) {
+    const vtts_hifigan_cfg& c = h->cfg;
+    const int mb = pick_microbatch(h, B, T);
+    const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * 2, 256);
+    char* bufX = static_cast<char*>(ws) + 0 * per;
+    char* bufT = static_cast<char*>(ws) + 1 * per;
+    char* bufC = static_cast<char*>(ws) + 2 * per;
+    char* bufS = static_cast<char*>(ws) + 3 * per;
+    const int nk = c.num_kernels;
+    const long wav_len = (long)h->hop * T;
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = std::min(mb, B - b0);
+        int rc;
+        {
+            const Layer& l = h->layers[h->idx_pre];
+            rc = run_layer_bf16(h, l, mel + (size_t)b0 * T * c.num_mels, c.num_mels, c.num_mels, nb, T, 1.0f, 0.1f, nullptr, bufS, 0, 1.f, s);
+            if (rc) return rc;
+            if (tap.name && !strcmp(tap.name, "conv_pre")) {
+                rc = tap_copy_bf16(bufS, tap.out + (size_t)b0 * l.cout * T, (size_t)nb * l.cout * T, s);
+                if (rc) return rc;
+            }
+        }
+        long L = T;
+        for (int i = 0; i < c.num_upsamples; ++i) {
+            const Layer& up = h->layers[h->idx_ups[i]];
+            rc = run_layer_bf16(h, up, bufS, up.cin, up.cin, nb, (int)L, 1.0f, 1.0f, nullptr, bufX, 0, 1.f, s);
+            if (rc) return rc;
+            L *= up.stride;
+            const int C = up.cout;
+            const size_t CL = (size_t)C * L;
+            if (tap.name && !strncmp(tap.name, "ups_", 4) && atoi(tap.name + 4) == i) {
+                rc = tap_copy_bf16(bufX, tap.out + (size_t)b0 * CL, (size_t)nb * CL, s);
+                if (rc) return rc;
+            }
+            const float next_slope = (i + 1 < c.num_upsamples) ? 0.1f : 0.01f;  // model.py:112 / :122
+            for (int j = 0; j < nk; ++j) {
+                const int base = h->idx_res[i * nk + j];
+                const char* cur = bufX;
+                for (int z = 0; z < 3; ++z) {
+                    const Layer& c1 = h->layers[base + 2 * z];
+                    const Layer& c2 = h->layers[base + 2 * z + 1];
+                    rc = run_layer_bf16(h, c1, cur, C, C, nb, (int)L, 0.1f, 0.1f, nullptr, bufT, 0, 1.f, s);
+                    if (rc) return rc;
+                    if (z < 2) {
+                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, 1.0f, cur, bufC, 0, 1.f, s);
+                        cur = bufC;
+                    } else {
+                        const bool last = (j == nk - 1);
+                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, last ? next_slope : 1.0f, cur, bufS, j > 0 ? 1 : 0,
+                                            last ? (float)nk : 1.0f, s);
+                    }
+                    if (rc) return rc;
+                }
+            }
+            if (tap.name && !strncmp(tap.name, "mrf_", 4) && atoi(tap.name + 4) == i) {
+                rc = tap_copy_bf16(bufS, tap.out + (size_t)b0 * CL, (size_t)nb * CL, s);
+                if (rc) return rc;
+            }
+        }
+        {
+            const Layer& l = h->layers[h->idx_post];
+            BConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = bufS;
+            a.wf = reinterpret_cast<const float*>(h->blob + l.off_w);
+            a.bias = reinterpret_cast<const float*>(h->blob + l.off_b);
+            a.B = nb;
+            a.L = (int)L;
+            float* pre = (tap.name && !strcmp(tap.name, "pre_tanh")) ? tap.out + (size_t)b0 * wav_len : nullptr;
+            hipError_t e = launch_conv_post_bf16(a, wav + (size_t)b0 * wav_len, pre, s);
+            if (e != hipSuccess) return fail(VTTS_ERR_HIP, "conv_post launch failed: %s", hipGetErrorString(e));
+        }
+    }
+    return VTTS_OK;
+}
+
 int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, size_t ws_bytes, hipStream_t s,
                  Taps tap) {
     if (!h->blob) return fail(VTTS_ERR_STATE, "forward() before pack()/bind_packed()");
@@ -296,6 +496,8 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
     vtts_hifigan_workspace_bytes(h, B, T, &need);
     if (ws_bytes < need || !ws) return fail(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(VTTS_ERR_INVALID, "workspace must be 256-B aligned");
+
+    if (h->dtype == VTTS_BF16) return forward_bf16(h, mel, B, T, wav, ws, s, tap);
 
     const vtts_hifigan_cfg& c = h->cfg;
     const int mb = pick_microbatch(h, B, T);
@@ -381,7 +583,7 @@ VTTS_API const char* vtts_last_error(void) { return g_last_error.c_str(); }
 VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dtype, vtts_hifigan** out) {
     if (!cfg || !out) return fail(VTTS_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (dtype != VTTS_F32) return fail(VTTS_ERR_INVALID, "dtype %d not available in this build (only VTTS_F32)", dtype);
+    if (dtype != VTTS_F32 && dtype != VTTS_BF16) return fail(VTTS_ERR_INVALID, "unknown dtype %d", dtype);
     if (cfg->num_upsamples < 1 || cfg->num_upsamples > VTTS_MAX_UPSAMPLES)
         return fail(VTTS_ERR_INVALID, "num_upsamples %d out of range", cfg->num_upsamples);
     if (cfg->num_kernels < 1 || cfg->num_kernels > VTTS_MAX_KERNELS)
@@ -408,7 +610,11 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
     h->cfg = *cfg;
     h->device = device;
     h->dtype = dtype;
-    build_layers(h);
+    const int rc = build_layers(h);
+    if (rc != VTTS_OK) {
+        delete h;
+        return rc;
+    }
     *out = h;
     return VTTS_OK;
 }
@@ -484,7 +690,38 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
     for (auto& l : h->layers)
         if (!l.have_w || !l.have_b) return fail(VTTS_ERR_MISSING, "parameter %s/%s was never set", l.key.c_str(), l.have_w ? "b" : "w");
     std::vector<char> host(h->blob_bytes, 0);
+    if (h->dtype == VTTS_BF16) {
+        for (auto& l : h->layers) {
+            float* bb = reinterpret_cast<float*>(host.data() + l.off_b);
+            for (int i = 0; i < l.coutp; ++i) bb[i] = l.b[i % l.cout];  // transposed conv rows are (phase, co)
+            if (l.bcls < BCLS_NONE) {  // conv_post keeps plain fp32 weights
+                memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
+                continue;
+            }
+            const BPackGeom g = bf16_pack_geom(l.bcls, l.kind == KIND_CONVT ? 3 : l.k);
+            if (l.kind == KIND_CONVT) {
+                // ConvTranspose1d(k = 2s) == Conv1d(Cin -> s*Cout, k = 3, pad 1) on channels-last data:
+                // phase r (group g = r / (s/2)) reads frames q + g - 1 + m (m = 0,1) through tap
+                // j = s*(g - 1 + m) + pad_a - r; the third frame of each phase gets zero weights.
+                const int sdt = l.stride, coutp = l.coutp;
+                std::vector<float> wc((size_t)3 * l.cin * coutp, 0.f);
+                for (int r = 0; r < sdt; ++r) {
+                    const int gq = r / (sdt / 2);
+                    for (int m = 0; m < 2; ++m) {
+                        const int f = gq + m, j = sdt * (gq - 1 + m) + l.pad_a - r;
+                        for (int co = 0; co < l.cout; ++co)
+                            for (int ci = 0; ci < l.cin; ++ci)
+                                wc[((size_t)f * l.cin + ci) * coutp + r * l.cout + co] = l.w[((size_t)j * l.cout + co) * l.cin + ci];
+                    }
+                }
+                bf16_pack(wc.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
+            } else {
+                bf16_pack(l.w.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
+            }
+        }
+    }
     for (auto& l : h->layers) {
+        if (h->dtype == VTTS_BF16) break;
         memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
         memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
         if (l.has_wp && l.kind == KIND_CONV)
@@ -511,7 +748,8 @@ VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, s
     if (!h || !bytes) return fail(VTTS_ERR_INVALID, "null argument");
     if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive");
     const int mb = pick_microbatch(h, B, T);
-    *bytes = 4 * align_up(max_act_elems(h, T) * (size_t)mb * sizeof(float), 256);
+    const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
+    *bytes = 4 * align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
     return VTTS_OK;
 }
 
@@ -565,6 +803,43 @@ VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const flo
     if (!l) return fail(VTTS_ERR_INVALID, "unknown module '%s'", key);
     const bool is_pre = (l == &h->layers[h->idx_pre]);
     const bool is_post = (l == &h->layers[h->idx_post]);
+    if (h->dtype == VTTS_BF16) {
+        // test hook: fp32 channels-last in/out, converted through temporary bf16 buffers
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const size_t nx = (size_t)B * L * l->cin, ny = (size_t)B * L * (l->kind == KIND_CONVT ? l->stride : 1) * l->cout;
+        void *xb = nullptr, *rb = nullptr, *yb = nullptr;
+        int rc = VTTS_OK;
+        if (is_post) {
+            HIP_TRY(hipMalloc(&xb, nx * 2));
+            if (launch_f32_to_bf16(x_dev, xb, nx, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+            BConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = xb;
+            a.wf = reinterpret_cast<const float*>(h->blob + l->off_w);
+            a.bias = reinterpret_cast<const float*>(h->blob + l->off_b);
+            a.B = B;
+            a.L = L;
+            if (!rc && launch_conv_post_bf16(a, y_dev, nullptr, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conv_post launch failed");
+        } else {
+            HIP_TRY(hipMalloc(&yb, ny * 2));
+            if (!is_pre) {
+                HIP_TRY(hipMalloc(&xb, nx * 2));
+                if (launch_f32_to_bf16(x_dev, xb, nx, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+            }
+            if (res_dev) {
+                HIP_TRY(hipMalloc(&rb, ny * 2));
+                if (launch_f32_to_bf16(res_dev, rb, ny, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+            }
+            if (!rc) rc = run_layer_bf16(h, *l, is_pre ? static_cast<const void*>(x_dev) : xb, l->cin, l->cin, B, L, slope_in, 1.0f, rb, yb, 0, 1.f, st);
+            if (!rc && launch_bf16_to_f32(yb, y_dev, ny, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+        }
+        hipError_t e = hipStreamSynchronize(st);
+        if (xb) (void)hipFree(xb);
+        if (rb) (void)hipFree(rb);
+        if (yb) (void)hipFree(yb);
+        if (!rc && e != hipSuccess) rc = fail(VTTS_ERR_HIP, "run_module failed: %s", hipGetErrorString(e));
+        return rc;
+    }
     Act x = is_pre ? Act{x_dev, (long)L * l->cin, 1, l->cin} : Act{x_dev, (long)l->cin * L, L, 1};
     return run_layer(h, *l, x, B, L, slope_in, res_dev, y_dev, ACC_STORE, 1.f, is_post ? 1 : 0, nullptr,
                      static_cast<hipStream_t>(stream));

@@ -61,4 +61,36 @@ hipError_t launch_convT1d_f32_mfma(const ConvArgs& a, hipStream_t s);
 bool conv_post_fast_supported(int Cin, int Cout, int K, int L);
 hipError_t launch_conv_post_fast(const ConvArgs& a, hipStream_t s);
 
+// =================================================================================================
+// bf16 path: kernels_bf16.hip  (channels-last activations, v_mfma_f32_32x32x16_bf16)
+// =================================================================================================
+enum BClass : int { BCLS_NONE = -1, BCLS_RES256 = 0, BCLS_RES128, BCLS_RES64, BCLS_RES32, BCLS_PRE, BCLS_UP0, BCLS_UP1, BCLS_UP2, BCLS_UP3 };
+
+struct BConvArgs {
+    const void* x;        // input activations: bf16 [B][L][x_pitch]  (fp32 for conv_pre)
+    const void* wp;       // packed bf16 weights (A-fragment-ordered slabs)
+    const float* wf;      // plain fp32 weights (conv_post only)
+    const float* bias;    // fp32 [COUTP]
+    const void* res;      // optional residual, bf16 [B][L][COUTP], or nullptr
+    void* y;              // output bf16 [B][L][COUTP]
+    int B, L;
+    int x_pitch;          // elements per input row in global memory
+    int cin_real;         // valid input channels (conv_pre: 80)
+    int dil, pad;
+    float slope_in;       // LeakyReLU applied to the input while staging (1 = producer already did it)
+    float slope_out;      // LeakyReLU applied to the stored output (the consumer's activation), 1 = none
+    int acc_add;          // y = y + v   (MRF accumulate)
+    float div;            // then v / div (MRF mean), 1 = none
+};
+
+struct BPackGeom { int cinp, ckc, coutp, ks, mt, tg; };
+
+hipError_t launch_conv_bf16(int cls, int K, const BConvArgs& a, hipStream_t s);
+BPackGeom bf16_pack_geom(int cls, int K);
+size_t bf16_packed_bytes(const BPackGeom& g);
+void bf16_pack(const float* Wc, int cin_real, const BPackGeom& g, unsigned short* out);
+hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
+hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
+hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
+
 }  // namespace vtts

@@ -187,16 +187,22 @@ class Generator:
         return out, tap_t
 
     def run_module(self, key: str, x: torch.Tensor, slope_in: float = 1.0, res: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Run one convolution module (per-layer KATs).  ``x`` is ``[B, C, L]`` channel-major
-        (``[B, L, num_mels]`` for conv_pre); returns ``[B, Cout, Lout]``."""
+        """Run one convolution module (per-layer KATs).
+        fp32 handle: ``x`` is ``[B, C, L]`` channel-major (``[B, L, num_mels]`` for conv_pre) -> ``[B, Cout, Lout]``.
+        bf16 handle: everything is channels-last fp32, ``x`` ``[B, L, C]`` -> ``[B, Lout, Cout]`` (``[B, Lout]`` for conv_post)."""
         spec = {s.key: s for s in conv_specs(self.cfg)}[key]
         x = x.contiguous()
-        if key == "generator/~/conv1_d":
+        channels_last = self.dtype_name == "bf16" or key == "generator/~/conv1_d"
+        if channels_last:
             B, L, _ = x.shape
         else:
             B, _, L = x.shape
         lout = L * spec.stride
-        y = torch.empty((B, spec.cout, lout), dtype=torch.float32, device=self.device)
+        if self.dtype_name == "bf16":
+            shape = (B, lout) if key == "generator/~/conv1_d_1" else (B, lout, spec.cout)
+        else:
+            shape = (B, spec.cout, lout)
+        y = torch.empty(shape, dtype=torch.float32, device=self.device)
         if res is not None:
             res = res.contiguous()
         stream = torch.cuda.current_stream(self.device)
