@@ -15,10 +15,10 @@
 //               registers.  Rows are 16-byte-slot XOR-swizzled so the MFMA B fragment (lane = time row,
 //               8 consecutive channels = one ds_read_b128) is bank-conflict-free for every row pitch.
 //               The K taps of the convolution are K row-shifted views of this one tile.
-//   * A slabs : weights pre-packed on the host in A-fragment order, streamed L2 -> VGPR -> LDS in slabs
-//               of TG taps x CKC channels (<= 32 KiB), double-buffered: the loads for slab s+1 are issued
-//               before the MFMAs of slab s and written to the other buffer after them (one barrier per
-//               slab).  Weight traffic from L2 is 2 B / (2*NT) FLOP -> NT = 256..512.
+//   * A slabs : weights pre-packed on the host in A-fragment order, streamed L2 -> LDS by LDS-DMA
+//               (global_load_lds_dwordx4) in slabs of TG taps x CKC channels (<= 32 KiB), double-buffered:
+//               slab s+1 is in flight while slab s feeds the MFMAs (one barrier per slab).
+//               Weight traffic from L2 is 2 B / (2*NT) FLOP -> NT = 256..512.
 //   * epilogue: accumulators + bias go through LDS as an fp32 [NT][MT] tile so that every global access
 //               (residual read, MRF accumulator read, output write) is a full-row coalesced 16-byte
 //               access; residual add, MRF sum / mean, the consumer's LeakyReLU and the bf16 rounding
@@ -36,6 +36,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     f32x2 v = {lo, hi};
@@ -78,6 +80,7 @@ struct BTile {
     static_assert(CINP % CKC == 0 && CKC % 16 == 0 && COUTP % MT == 0, "channel tiling");
     static_assert(SPR == 4 || SPR == 8 || SPR == 16, "row pitch 64/128/256 B");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(SLAB_UNITS % 64 == 0, "slab = whole wave-instructions of LDS-DMA");
 };
 
 template <class T>
@@ -112,21 +115,16 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
-    uint4 areg[APT];
-    auto load_slab = [&](int s) {
+    // A slab s -> LDS buffer `buf`, asynchronously (LDS-DMA: global_load_lds_dwordx4, no VGPR round trip).
+    // Destination = wave-uniform base + lane*16, which is exactly the fragment-ordered slab image.
+    auto issue_slab = [&](int s, int buf) {
         const uint4* src = wsl + (size_t)s * T::SLAB_UNITS;
+        unsigned char* dst = ab + buf * T::SLAB_BYTES + (size_t)(wave * 64) * 16;
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int u = tid + i * THREADS;
-            if (APT * THREADS == T::SLAB_UNITS || u < T::SLAB_UNITS) areg[i] = src[u];
-        }
-    };
-    auto write_slab = [&](int buf) {
-        uint4* dst = reinterpret_cast<uint4*>(ab + buf * T::SLAB_BYTES);
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int u = tid + i * THREADS;
-            if (APT * THREADS == T::SLAB_UNITS || u < T::SLAB_UNITS) dst[u] = areg[i];
+            const int u0 = wave * 64 + i * THREADS;  // wave-uniform
+            if (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + u0 + lane), (lds_ptr_t)(dst + (size_t)i * THREADS * 16), 16, 0, 0);
         }
     };
     auto stage_x = [&](int cc) {
@@ -168,10 +166,9 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         }
     };
 
-    load_slab(0);
+    issue_slab(0, 0);
     stage_x(0);
-    write_slab(0);
-    __syncthreads();
+    __syncthreads();  // also drains the LDS-DMA (the barrier's release waits vmcnt(0))
 
     const int dil = a.dil;
     const int rowbase0 = wn * (NT / WN) + l31 - a.pad + PA;
@@ -182,8 +179,9 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
             __syncthreads();
         }
         for (int sl = 0; sl < NSL; ++sl, ++s) {
-            const bool has_next = (s + 1) < NCC * NSL;
-            if (has_next) load_slab(s + 1);
+            // slab s+1 streams into the other buffer while slab s feeds the MFMAs; every wave is past the
+            // barrier that ended slab s-1, so nobody still reads that buffer
+            if ((s + 1) < NCC * NSL) issue_slab(s + 1, (s + 1) & 1);
             const unsigned char* abuf = ab + (T::NBUF == 2 ? (s & 1) * T::SLAB_BYTES : 0);
             const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
             for (int tj = 0; tj < ntaps; ++tj) {
@@ -211,8 +209,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
                             acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
                 }
             }
-            if (has_next) write_slab((s + 1) & 1);
-            __syncthreads();
+            __syncthreads();  // slab s consumed by all waves, slab s+1 landed (vmcnt(0) before the barrier)
         }
     }
 
