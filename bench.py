@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1024, help="mel frames per utterance")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--microbatch", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=0, help="micro-batches in flight on separate HIP streams (0 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
@@ -94,6 +95,8 @@ def main():
     gen = Generator(V1, device=dev, dtype=args.dtype)
     if args.microbatch:
         gen.set_option("microbatch", args.microbatch)
+    if args.streams:
+        gen.set_option("streams", args.streams)
     vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info)
 
     B, T = args.batch, args.frames
@@ -151,6 +154,7 @@ def main():
                 "samples_per_step": samples_per_step,
                 "parallelism": f"dp{n_gpus} utterance-sharded, weights broadcast once, no data-path collective",
                 "microbatch": gen.get_option("microbatch"),
+                "streams": gen.get_option("streams"),
             },
             "tflops_whole_job": value * FLOP_PER_SAMPLE / 1e12,
             "frac_of_mfma_peak_whole_forward": value * FLOP_PER_SAMPLE / 1e12 / (PEAK_TFLOPS[args.dtype] * n_gpus),

@@ -146,6 +146,8 @@ int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev
  * Engine options (tests / benchmarks):
  *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
  *   "microbatch" utterances processed per pass through the network (0 = auto)
+ *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
+ *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
  *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
  */

@@ -83,6 +83,9 @@ struct vtts_hifigan {
     int64_t opt_microbatch = 0;      // 0 auto
     int64_t opt_profile = 0;
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
+    int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
+    hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // profiling of the dominant kernel class
     int prof_C = 0, prof_K = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
@@ -155,9 +158,8 @@ int build_layers_bf16(vtts_hifigan* h) {
         }
     }
     h->blob_bytes = off;
-    char buf[96];
-    snprintf(buf, sizeof(buf), "conv_bf16_k<BTile<%d, %d, %d, %d", h->prof_C, h->prof_C > 128 ? 128 : h->prof_C, h->prof_C, h->prof_K);
-    h->prof_name = buf;
+    for (auto& l : h->layers)
+        if (l.kind == KIND_CONV && l.cin == h->prof_C && l.cout == h->prof_C && l.k == h->prof_K) h->prof_name = bf16_kernel_name(l.bcls, l.k);
     return VTTS_OK;
 }
 
@@ -406,23 +408,68 @@ struct Taps {
 };
 
 
+
+// Micro-batches are independent, so consecutive ones may run on different HIP streams: workgroups of
+// one micro-batch in an HBM phase (tile staging / epilogue) then share the CUs with workgroups of
+// another in its MFMA phase instead of every workgroup on the chip hitting HBM at the same time.
+int num_streams(const vtts_hifigan* h, int B, int T) {
+    const int mb = pick_microbatch(h, B, T);
+    const int nmb = (B + mb - 1) / mb;
+    int n = (int)h->opt_streams;
+    if (n > nmb) n = nmb;
+    return n < 1 ? 1 : n;
+}
+
+int fork_streams(vtts_hifigan* h, int n, hipStream_t s, hipStream_t* out) {
+    out[0] = s;
+    if (n <= 1) return VTTS_OK;
+    if (!h->ev_fork) {
+        HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < 3; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&h->side_streams[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+        }
+    }
+    HIP_TRY(hipEventRecord(h->ev_fork, s));
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipStreamWaitEvent(h->side_streams[i - 1], h->ev_fork, 0));
+        out[i] = h->side_streams[i - 1];
+    }
+    return VTTS_OK;
+}
+
+int join_streams(vtts_hifigan* h, int n, hipStream_t s) {
+    for (int i = 1; i < n; ++i) {
+        HIP_TRY(hipEventRecord(h->ev_join[i - 1], h->side_streams[i - 1]));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_join[i - 1], 0));
+    }
+    return VTTS_OK;
+}
+
 // bf16 schedule.  Same dataflow as the fp32 one, with two differences that only bf16 needs:
 //  * activations are channels-last bf16 [B][L][C] (a transposed convolution's [L][s*Cout] output IS the
 //    [s*L][Cout] tensor);
 //  * a tensor that is only ever consumed through LeakyReLU is stored already activated by its producer
 //    (in fp32, before the bf16 rounding): conv_pre -> ups_0, xt = c1(.) -> c2, MRF mean -> next ups / conv_post.
 //    Only the ResBlock's running x is stored raw (it is also the residual) and activated on load by c1.
-int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, hipStream_t s, Taps tap) {
+int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, hipStream_t s0, Taps tap) {
     const vtts_hifigan_cfg& c = h->cfg;
     const int mb = pick_microbatch(h, B, T);
     const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * 2, 256);
-    char* bufX = static_cast<char*>(ws) + 0 * per;
-    char* bufT = static_cast<char*>(ws) + 1 * per;
-    char* bufC = static_cast<char*>(ws) + 2 * per;
-    char* bufS = static_cast<char*>(ws) + 3 * per;
+    const int nstr = num_streams(h, B, T);
+    hipStream_t streams[4];
+    int rc0 = fork_streams(h, nstr, s0, streams);
+    if (rc0) return rc0;
     const int nk = c.num_kernels;
     const long wav_len = (long)h->hop * T;
     for (int b0 = 0; b0 < B; b0 += mb) {
+        const int si = (b0 / mb) % nstr;
+        hipStream_t s = streams[si];
+        char* wsb = static_cast<char*>(ws) + (size_t)si * 4 * per;
+        char* bufX = wsb + 0 * per;
+        char* bufT = wsb + 1 * per;
+        char* bufC = wsb + 2 * per;
+        char* bufS = wsb + 3 * per;
         const int nb = std::min(mb, B - b0);
         int rc;
         {
@@ -485,7 +532,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             if (e != hipSuccess) return fail(VTTS_ERR_HIP, "conv_post launch failed: %s", hipGetErrorString(e));
         }
     }
-    return VTTS_OK;
+    return join_streams(h, nstr, s0);
 }
 
 int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, size_t ws_bytes, hipStream_t s,
@@ -502,14 +549,22 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
     const vtts_hifigan_cfg& c = h->cfg;
     const int mb = pick_microbatch(h, B, T);
     const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * sizeof(float), 256);
-    float* bufX = reinterpret_cast<float*>(static_cast<char*>(ws) + 0 * per);   // stage input x (ups output)
-    float* bufT = reinterpret_cast<float*>(static_cast<char*>(ws) + 1 * per);   // xt inside a ResBlock pair
-    float* bufC = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * per);   // running x inside a ResBlock
-    float* bufS = reinterpret_cast<float*>(static_cast<char*>(ws) + 3 * per);   // MRF accumulator xs / stage output
+    const int nstr = num_streams(h, B, T);
+    hipStream_t streams[4];
+    hipStream_t s0 = s;
+    int rc0 = fork_streams(h, nstr, s0, streams);
+    if (rc0) return rc0;
     const int nk = c.num_kernels;
     const long wav_len = (long)h->hop * T;
 
     for (int b0 = 0; b0 < B; b0 += mb) {
+        const int si = (b0 / mb) % nstr;
+        hipStream_t s = streams[si];
+        char* wsb = static_cast<char*>(ws) + (size_t)si * 4 * per;
+        float* bufX = reinterpret_cast<float*>(wsb + 0 * per);   // stage input x (ups output)
+        float* bufT = reinterpret_cast<float*>(wsb + 1 * per);   // xt inside a ResBlock pair
+        float* bufC = reinterpret_cast<float*>(wsb + 2 * per);   // running x inside a ResBlock
+        float* bufS = reinterpret_cast<float*>(wsb + 3 * per);   // MRF accumulator xs / stage output
         const int nb = std::min(mb, B - b0);
         int rc;
         // conv_pre (model.py:110): mel [nb][T][num_mels] NWC -> S [nb][C0][T]
@@ -570,7 +625,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             if (rc) return rc;
         }
     }
-    return VTTS_OK;
+    return join_streams(h, nstr, s0);
 }
 
 }  // namespace
@@ -621,6 +676,11 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
 
 VTTS_API void vtts_hifigan_destroy(vtts_hifigan* h) {
     if (!h) return;
+    for (int i = 0; i < 3; ++i) {
+        if (h->side_streams[i]) (void)hipStreamDestroy(h->side_streams[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& p : h->prof_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -749,7 +809,7 @@ VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, s
     if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive");
     const int mb = pick_microbatch(h, B, T);
     const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
-    *bytes = 4 * align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
+    *bytes = (size_t)num_streams(h, B, T) * 4 * align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
     return VTTS_OK;
 }
 
@@ -853,6 +913,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "microbatch")) {
         if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
         h->opt_microbatch = value;
+    } else if (!strcmp(name, "streams")) {
+        if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
+        h->opt_streams = value;
     } else if (!strcmp(name, "tiles")) {
         if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "tiles must be 0 (auto), 1 (wide) or 2 (narrow)");
         h->opt_tiles = value;
@@ -870,6 +933,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "microbatch")) *value = h->opt_microbatch;
     else if (!strcmp(name, "profile")) *value = h->opt_profile;
     else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
+    else if (!strcmp(name, "streams")) *value = h->opt_streams;
     else if (!strcmp(name, "hop")) *value = h->hop;
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;
     else if (!strcmp(name, "profile_K")) *value = h->prof_K;

@@ -26,9 +26,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdio.h>
 #include <string.h>
 
 #include "vtts_internal.h"
+
+// timing ablations (never defined in the product build): results are wrong when any is set
+#ifndef VTTS_EXP_NOSTORE
+#define VTTS_EXP_NOSTORE 0
+#endif
+#ifndef VTTS_EXP_NOXLOAD
+#define VTTS_EXP_NOXLOAD 0
+#endif
+#ifndef VTTS_EXP_NOMFMA
+#define VTTS_EXP_NOMFMA 0
+#endif
+#ifndef VTTS_EXP_NOSLAB
+#define VTTS_EXP_NOSLAB 0
+#endif
 
 namespace vtts {
 
@@ -51,33 +66,35 @@ __device__ __forceinline__ unsigned lrelu_bf16x2(unsigned u, float s) {
     return pack_bf16x2(lrelu_f(bf16_lo(u), s), lrelu_f(bf16_hi(u), s));
 }
 
-template <int CINP_, int CKC_, int COUTP_, int KS_, int MT_, int NT_, int WM_, int WN_, int TG_, int PA_, bool IN_F32_>
+template <int CINP_, int XC_, int CKC_, int COUTP_, int KS_, int MT_, int NT_, int WM_, int WN_, int TG_, int PA_, bool IN_F32_>
 struct BTile {
-    static constexpr int CINP = CINP_, CKC = CKC_, COUTP = COUTP_, KS = KS_, MT = MT_, NT = NT_, WM = WM_, WN = WN_;
+    static constexpr int CINP = CINP_, XC = XC_, CKC = CKC_, COUTP = COUTP_, KS = KS_, MT = MT_, NT = NT_, WM = WM_, WN = WN_;
     static constexpr int TG = TG_, PA = PA_;
     static constexpr bool IN_F32 = IN_F32_;
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int MR = MT / WM / 32, NR = NT / WN / 32;
-    static constexpr int NCC = CINP / CKC;              // input-channel chunks
-    static constexpr int SPR = CKC / 8;                 // 16-byte slots per X row
-    static constexpr int P = CKC * 2;                   // X row pitch in bytes
+    static constexpr int NXC = CINP / XC;               // X-tile chunks (re-staged per chunk)
+    static constexpr int NCK = XC / CKC;                // weight-slab channel chunks per X chunk
+    static constexpr int SPR = XC / 8;                  // 16-byte slots per X row
+    static constexpr int P = XC * 2;                    // X row pitch in bytes
     static constexpr int RPB = 16 / SPR;                // X rows per 256-byte LDS bank row
     static constexpr int ROWS = NT + 2 * PA;
     static constexpr int X_BYTES = ROWS * P;
-    static constexpr int KSTEPS = CKC / 16;             // MFMA k-steps per tap per chunk
-    static constexpr int NSL = (KS + TG - 1) / TG;      // slabs per chunk
+    static constexpr int KSTEPS = CKC / 16;             // MFMA k-steps per tap per slab chunk
+    static constexpr int NSL = (KS + TG - 1) / TG;      // slabs per channel chunk
+    static constexpr int NSTOT = NXC * NCK * NSL;       // slabs per workgroup
     static constexpr int MB = MT / 32;                  // m-blocks per tile
     static constexpr int SLAB_BYTES = MT * TG * CKC * 2;
     static constexpr int SLAB_UNITS = SLAB_BYTES / 16;
     static constexpr int APT = (SLAB_UNITS + THREADS - 1) / THREADS;  // 16-byte slab units per thread
-    static constexpr int NBUF = (NSL * NCC > 1) ? 2 : 1;
+    static constexpr int NBUF = (NSTOT > 1) ? 2 : 1;
     static constexpr int XPT = (ROWS * SPR + THREADS - 1) / THREADS;  // X units per thread
     static constexpr int EP_PITCH = MT * 4 + 16;        // fp32 epilogue tile row pitch (bytes), conflict-free
     static constexpr int EP_BYTES = NT * EP_PITCH;
     static constexpr int MAIN_BYTES = X_BYTES + NBUF * SLAB_BYTES;
     static constexpr int LDS_BYTES = MAIN_BYTES > EP_BYTES ? MAIN_BYTES : EP_BYTES;
     static_assert(MT % (WM * 32) == 0 && NT % (WN * 32) == 0, "tile/wave mismatch");
-    static_assert(CINP % CKC == 0 && CKC % 16 == 0 && COUTP % MT == 0, "channel tiling");
+    static_assert(CINP % XC == 0 && XC % CKC == 0 && CKC % 16 == 0 && COUTP % MT == 0, "channel tiling");
     static_assert(SPR == 4 || SPR == 8 || SPR == 16, "row pitch 64/128/256 B");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(SLAB_UNITS % 64 == 0, "slab = whole wave-instructions of LDS-DMA");
@@ -85,9 +102,9 @@ struct BTile {
 
 template <class T>
 __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
-    constexpr int CKC = T::CKC, COUTP = T::COUTP, KS = T::KS, MT = T::MT, NT = T::NT, WN = T::WN, TG = T::TG, PA = T::PA;
-    constexpr int THREADS = T::THREADS, MR = T::MR, NR = T::NR, NCC = T::NCC, SPR = T::SPR, P = T::P, RPB = T::RPB;
-    constexpr int ROWS = T::ROWS, KSTEPS = T::KSTEPS, NSL = T::NSL, MB = T::MB, APT = T::APT, XPT = T::XPT;
+    constexpr int XC = T::XC, CKC = T::CKC, COUTP = T::COUTP, KS = T::KS, MT = T::MT, NT = T::NT, WN = T::WN, TG = T::TG, PA = T::PA;
+    constexpr int THREADS = T::THREADS, MR = T::MR, NR = T::NR, NXC = T::NXC, NCK = T::NCK, SPR = T::SPR, P = T::P, RPB = T::RPB;
+    constexpr int ROWS = T::ROWS, KSTEPS = T::KSTEPS, NSL = T::NSL, NSTOT = T::NSTOT, MB = T::MB, APT = T::APT, XPT = T::XPT;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* xt = lds;
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
     const int b = blockIdx.z;
     const int L = a.L;
 
-    const uint4* __restrict__ wsl = reinterpret_cast<const uint4*>(a.wp) + (size_t)mtile * (NCC * NSL) * T::SLAB_UNITS;
+    const uint4* __restrict__ wsl = reinterpret_cast<const uint4*>(a.wp) + (size_t)mtile * NSTOT * T::SLAB_UNITS;
 
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int u0 = wave * 64 + i * THREADS;  // wave-uniform
-            if (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS)
+            if (!VTTS_EXP_NOSLAB && (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS))
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + u0 + lane), (lds_ptr_t)(dst + (size_t)i * THREADS * 16), 16, 0, 0);
         }
     };
@@ -135,8 +152,8 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
             const int row = u / SPR, c = u % SPR;
             const int t = t0 - PA + row;
             v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (u < ROWS * SPR && t >= 0 && t < L) {
-                const int ch = cc * CKC + c * 8;
+            if (!VTTS_EXP_NOXLOAD && u < ROWS * SPR && t >= 0 && t < L) {
+                const int ch = cc * XC + c * 8;
                 if constexpr (T::IN_F32) {
                     if (ch < a.cin_real) {
                         const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ((size_t)b * L + t) * a.x_pitch + ch);
@@ -173,43 +190,68 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
     const int dil = a.dil;
     const int rowbase0 = wn * (NT / WN) + l31 - a.pad + PA;
     int s = 0;
-    for (int cc = 0; cc < NCC; ++cc) {
-        if (cc > 0) {
-            stage_x(cc);  // every wave passed the barrier that ended the previous slab: the old X is dead
+    for (int xc = 0; xc < NXC; ++xc) {
+        if (xc > 0) {
+            stage_x(xc);  // every wave passed the barrier that ended the previous slab: the old X is dead
             __syncthreads();
         }
-        for (int sl = 0; sl < NSL; ++sl, ++s) {
-            // slab s+1 streams into the other buffer while slab s feeds the MFMAs; every wave is past the
-            // barrier that ended slab s-1, so nobody still reads that buffer
-            if ((s + 1) < NCC * NSL) issue_slab(s + 1, (s + 1) & 1);
-            const unsigned char* abuf = ab + (T::NBUF == 2 ? (s & 1) * T::SLAB_BYTES : 0);
-            const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
-            for (int tj = 0; tj < ntaps; ++tj) {
-                const int rowb = rowbase0 + (sl * TG + tj) * dil;
+        for (int ck = 0; ck < NCK; ++ck) {
+            for (int sl = 0; sl < NSL; ++sl, ++s) {
+                // slab s+1 streams into the other buffer while slab s feeds the MFMAs; every wave is past the
+                // barrier that ended slab s-1, so nobody still reads that buffer
+                if ((s + 1) < NSTOT) issue_slab(s + 1, (s + 1) & 1);
+                const unsigned char* abuf = ab + (T::NBUF == 2 ? (s & 1) * T::SLAB_BYTES : 0) + (size_t)(wm * MR) * 1024 + lane * 16;
+                const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
+                const int slot0 = ck * (CKC / 8) + lh;
+
+                // software pipeline over (tap, k-step): fragments of step q+1 are read while step q's MFMAs issue
                 int rowoff[NR], rowswz[NR];
+                auto set_rows = [&](int tj) {
+                    const int rowb = rowbase0 + (sl * TG + tj) * dil;
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    const int row = rowb + nr * 32;
-                    rowoff[nr] = row * P;
-                    rowswz[nr] = (row / RPB) & (SPR - 1);
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int row = rowb + nr * 32;
+                        rowoff[nr] = row * P;
+                        rowswz[nr] = (row / RPB) & (SPR - 1);
+                    }
+                };
+                bf16x8 af[MR], bf[NR], afn[MR], bfn[NR];
+                set_rows(0);
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) bf[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + ((slot0 ^ rowswz[nr]) << 4));
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) af[mr] = *reinterpret_cast<const bf16x8*>(abuf + mr * 1024);
+                for (int tj = 0; tj < ntaps; ++tj) {
+                    const unsigned char* aslab = abuf + (size_t)(tj * KSTEPS) * MB * 1024;
+#pragma unroll
+                    for (int ks = 0; ks < KSTEPS; ++ks) {
+                        if (ks + 1 < KSTEPS) {
+#pragma unroll
+                            for (int nr = 0; nr < NR; ++nr)
+                                bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + (((slot0 + (ks + 1) * 2) ^ rowswz[nr]) << 4));
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + ((ks + 1) * MB + mr) * 1024);
+                        } else if (tj + 1 < ntaps) {
+                            set_rows(tj + 1);
+#pragma unroll
+                            for (int nr = 0; nr < NR; ++nr) bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + ((slot0 ^ rowswz[nr]) << 4));
+#pragma unroll
+                            for (int mr = 0; mr < MR; ++mr) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + (KSTEPS * MB + mr) * 1024);
+                        }
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                            for (int nr = 0; nr < NR; ++nr)
+                                if (!VTTS_EXP_NOMFMA) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
+                                else acc[mr][nr][0] += (float)af[mr][0] * (float)bf[nr][0];
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) af[mr] = afn[mr];
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) bf[nr] = bfn[nr];
+                    }
                 }
-                const unsigned char* aslab = abuf + ((size_t)(tj * KSTEPS) * MB + wm * MR) * 1024 + lane * 16;
-#pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    bf16x8 bf[NR], af[MR];
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        bf[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + (((ks * 2 + lh) ^ rowswz[nr]) << 4));
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) af[mr] = *reinterpret_cast<const bf16x8*>(aslab + (ks * MB + mr) * 1024);
-#pragma unroll
-                    for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                        for (int nr = 0; nr < NR; ++nr)
-                            acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
-                }
+                __syncthreads();  // slab s consumed by all waves, slab s+1 landed (vmcnt(0) before the barrier)
             }
-            __syncthreads();  // slab s consumed by all waves, slab s+1 landed (vmcnt(0) before the barrier)
         }
     }
 
@@ -246,6 +288,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         const int row = u / UPR, c8 = u % UPR;
         const int t = t0 + row;
         if (t >= L) continue;
+        if (VTTS_EXP_NOSTORE && a.slope_out != 12345.f) continue;
         const float4 p0 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8);
         const float4 p1 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8 + 4);
         float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
@@ -273,16 +316,18 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
 }
 
 // ---- tile table ------------------------------------------------------------------------------------
-//                        CINP CKC COUTP KS  MT   NT  WM WN TG PA  IN_F32
-template <int KS> using BRes256 = BTile<256, 128, 256, KS, 128, 256, 2, 4, 1, (KS - 1) / 2 * 5, false>;
-template <int KS> using BRes128 = BTile<128, 128, 128, KS, 128, 256, 2, 4, 1, (KS - 1) / 2 * 5, false>;
-template <int KS> using BRes64 = BTile<64, 64, 64, KS, 64, 512, 1, 8, (KS < 4 ? KS : 4), (KS - 1) / 2 * 5, false>;
-template <int KS> using BRes32 = BTile<32, 32, 32, KS, 32, 512, 1, 8, KS, (KS - 1) / 2 * 5, false>;
-using BPre = BTile<128, 128, 512, 7, 128, 256, 2, 4, 1, 3, true>;    // conv_pre: 80 (padded to 128) -> 512
-using BUp0 = BTile<512, 128, 2048, 3, 128, 256, 2, 4, 1, 1, false>;  // ups_0 as Conv1d(512 -> 8*256, k=3)
-using BUp1 = BTile<256, 128, 1024, 3, 128, 256, 2, 4, 1, 1, false>;  // ups_1 as Conv1d(256 -> 8*128, k=3)
-using BUp2 = BTile<128, 128, 128, 3, 128, 256, 2, 4, 1, 1, false>;   // ups_2 as Conv1d(128 -> 2*64,  k=3)
-using BUp3 = BTile<64, 64, 64, 3, 64, 512, 1, 8, 3, 1, false>;       // ups_3 as Conv1d(64  -> 2*32,  k=3)
+// Two workgroups per CU (<= 80 KiB LDS each) so that one workgroup's HBM phases (X staging, epilogue)
+// overlap the other's MFMA phase.
+//                        CINP XC  CKC COUTP KS  MT   NT  WM WN TG PA  IN_F32
+template <int KS> using BRes256 = BTile<256, 128, 64, 256, KS, 128, 128, 2, 2, 1, (KS - 1) / 2 * 5, false>;
+template <int KS> using BRes128 = BTile<128, 128, 64, 128, KS, 128, 128, 2, 2, 1, (KS - 1) / 2 * 5, false>;
+template <int KS> using BRes64 = BTile<64, 64, 64, 64, KS, 64, 256, 1, 4, 2, (KS - 1) / 2 * 5, false>;
+template <int KS> using BRes32 = BTile<32, 32, 32, 32, KS, 32, 256, 1, 4, KS, (KS - 1) / 2 * 5, false>;
+using BPre = BTile<128, 128, 64, 512, 7, 128, 128, 2, 2, 1, 3, true>;    // conv_pre: 80 (padded to 128) -> 512
+using BUp0 = BTile<512, 128, 64, 2048, 3, 128, 128, 2, 2, 1, 1, false>;  // ups_0 as Conv1d(512 -> 8*256, k=3)
+using BUp1 = BTile<256, 128, 64, 1024, 3, 128, 128, 2, 2, 1, 1, false>;  // ups_1 as Conv1d(256 -> 8*128, k=3)
+using BUp2 = BTile<128, 128, 64, 128, 3, 128, 128, 2, 2, 1, 1, false>;   // ups_2 as Conv1d(128 -> 2*64,  k=3)
+using BUp3 = BTile<64, 64, 64, 64, 3, 64, 256, 1, 4, 3, 1, false>;       // ups_3 as Conv1d(64  -> 2*32,  k=3)
 
 template <class T>
 static hipError_t launch_b(const BConvArgs& a, hipStream_t s) {
@@ -325,19 +370,28 @@ hipError_t launch_conv_bf16(int cls, int K, const BConvArgs& a, hipStream_t s) {
 // tile geometry the host-side packer needs, per class
 BPackGeom bf16_pack_geom(int cls, int K) {
     auto mk = [](int cinp, int ckc, int coutp, int ks, int mt, int tg) { return BPackGeom{cinp, ckc, coutp, ks, mt, tg}; };
-    const int tg64 = K < 4 ? K : 4;
+    (void)K;
     switch (cls) {
-        case BCLS_RES256: return mk(256, 128, 256, K, 128, 1);
-        case BCLS_RES128: return mk(128, 128, 128, K, 128, 1);
-        case BCLS_RES64: return mk(64, 64, 64, K, 64, tg64);
+        case BCLS_RES256: return mk(256, 64, 256, K, 128, 1);
+        case BCLS_RES128: return mk(128, 64, 128, K, 128, 1);
+        case BCLS_RES64: return mk(64, 64, 64, K, 64, 2);
         case BCLS_RES32: return mk(32, 32, 32, K, 32, K);
-        case BCLS_PRE: return mk(128, 128, 512, 7, 128, 1);
-        case BCLS_UP0: return mk(512, 128, 2048, 3, 128, 1);
-        case BCLS_UP1: return mk(256, 128, 1024, 3, 128, 1);
-        case BCLS_UP2: return mk(128, 128, 128, 3, 128, 1);
+        case BCLS_PRE: return mk(128, 64, 512, 7, 128, 1);
+        case BCLS_UP0: return mk(512, 64, 2048, 3, 128, 1);
+        case BCLS_UP1: return mk(256, 64, 1024, 3, 128, 1);
+        case BCLS_UP2: return mk(128, 64, 128, 3, 128, 1);
         case BCLS_UP3: return mk(64, 64, 64, 3, 64, 3);
     }
     return mk(0, 0, 0, 0, 0, 0);
+}
+
+// name prefix of the instantiation, as rocprofv3 prints it
+const char* bf16_kernel_name(int cls, int K) {
+    static thread_local char buf[96];
+    const BPackGeom g = bf16_pack_geom(cls, K);
+    const int xc = g.cinp < 128 ? g.cinp : 128;
+    snprintf(buf, sizeof(buf), "conv_bf16_k<BTile<%d, %d, %d, %d, %d,", g.cinp, xc, g.ckc, g.coutp, g.ks);
+    return buf;
 }
 
 static unsigned short f32_to_bf16_rne(float f) {

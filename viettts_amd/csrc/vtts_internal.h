@@ -87,6 +87,7 @@ struct BPackGeom { int cinp, ckc, coutp, ks, mt, tg; };
 
 hipError_t launch_conv_bf16(int cls, int K, const BConvArgs& a, hipStream_t s);
 BPackGeom bf16_pack_geom(int cls, int K);
+const char* bf16_kernel_name(int cls, int K);
 size_t bf16_packed_bytes(const BPackGeom& g);
 void bf16_pack(const float* Wc, int cin_real, const BPackGeom& g, unsigned short* out);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);

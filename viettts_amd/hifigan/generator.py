@@ -115,7 +115,7 @@ class Generator:
     # ---- options --------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
         _lib.check(self.lib, self.lib.vtts_hifigan_set_option(self._h, name.encode(), int(value)))
-        if name == "microbatch":
+        if name in ("microbatch", "streams"):
             self._ws = None
 
     def get_option(self, name: str) -> int:
