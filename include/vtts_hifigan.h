@@ -143,9 +143,18 @@ int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev
                             float slope_in, const float* res_dev, float* y_dev, vtts_stream stream);
 
 /*
+ * VTTS_BF16 handles only: run ONE fused ResBlock1 pair  x' = convs2_z(lrelu(convs1_z(lrelu(x)))) + x
+ * (model.py:45-50) named by its first convolution's key.  x_dev / y_dev are fp32 [B, L, C]
+ * channels-last, rounded to bf16 on the way in; the call synchronises the stream.
+ */
+int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_dev, int B, int L,
+                          float* y_dev, vtts_stream stream);
+
+/*
  * Engine options (tests / benchmarks):
  *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
  *   "microbatch" utterances processed per pass through the network (0 = auto)
+ *   "fuse"      bf16: 1 = fused ResBlock-pair kernel (default), 0 = one kernel per convolution
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
  *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow

@@ -45,6 +45,7 @@ EXPORTS = (
     "vtts_hifigan_tap_elems",
     "vtts_hifigan_forward_tap",
     "vtts_hifigan_run_module",
+    "vtts_hifigan_run_pair",
     "vtts_hifigan_set_option",
     "vtts_hifigan_get_option",
     "vtts_hifigan_profile_read",
@@ -142,6 +143,7 @@ def load(path=None) -> C.CDLL:
         "vtts_hifigan_tap_elems": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(sz)]),
         "vtts_hifigan_forward_tap": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, cp, vp]),
         "vtts_hifigan_run_module": (C.c_int, [vp, cp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
+        "vtts_hifigan_run_pair": (C.c_int, [vp, cp, vp, C.c_int, C.c_int, vp, vp]),
         "vtts_hifigan_set_option": (C.c_int, [vp, cp, i64]),
         "vtts_hifigan_get_option": (C.c_int, [vp, cp, C.POINTER(i64)]),
         "vtts_hifigan_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),

@@ -61,6 +61,9 @@ struct Layer {
     int bcls = BCLS_NONE;
     size_t off_wb = 0, wb_bytes = 0;
     int coutp = 0;  // GEMM rows: cout, or stride*cout for a transposed convolution run as Conv1d(k=3)
+    // fused pair (this layer = convs1_z, next layer = convs2_z): [c1 slabs][c2 slabs] + [b1][b2]
+    bool has_pair = false;
+    size_t off_pw = 0, pw_bytes = 0, off_pb = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -83,6 +86,7 @@ struct vtts_hifigan {
     int64_t opt_microbatch = 0;      // 0 auto
     int64_t opt_profile = 0;
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
+    int64_t opt_fuse = 1;            // bf16: fused ResBlock pair kernel (1) or one kernel per convolution (0)
     int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -91,7 +95,7 @@ struct vtts_hifigan {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     size_t prof_used = 0;
     double prof_flops = 0.0;
-    std::string prof_name;
+    std::string prof_name, prof_name_pair;
 };
 
 namespace {
@@ -157,9 +161,23 @@ int build_layers_bf16(vtts_hifigan* h) {
             }
         }
     }
+    for (size_t r = 0; r < h->idx_res.size(); ++r) {
+        for (int z = 0; z < 3; ++z) {
+            Layer& c1 = h->layers[h->idx_res[r] + 2 * z];
+            const Layer& c2 = h->layers[h->idx_res[r] + 2 * z + 1];
+            if (!pair_bf16_supported(c1.cin, c1.k, c1.dil) || c2.dil != 1 || c2.k != c1.k) continue;
+            c1.has_pair = true;
+            c1.pw_bytes = 2 * bf16_packed_bytes(pair_pack_geom(c1.cin, c1.k));
+            c1.off_pw = off;
+            off = align_up(off + c1.pw_bytes, 256);
+            c1.off_pb = off;
+            off = align_up(off + (size_t)2 * c1.cin * sizeof(float), 256);
+        }
+    }
     h->blob_bytes = off;
     for (auto& l : h->layers)
         if (l.kind == KIND_CONV && l.cin == h->prof_C && l.cout == h->prof_C && l.k == h->prof_K) h->prof_name = bf16_kernel_name(l.bcls, l.k);
+    h->prof_name_pair = pair_kernel_name(h->prof_C, h->prof_K);
     return VTTS_OK;
 }
 
@@ -372,6 +390,44 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
     return VTTS_OK;
 }
 
+int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L, float slope_out, void* y, int acc_add, float div,
+                  hipStream_t s) {
+    BConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.wp = h->blob + c1.off_pw;
+    a.bias = reinterpret_cast<const float*>(h->blob + c1.off_pb);
+    a.y = y;
+    a.B = B;
+    a.L = L;
+    a.x_pitch = c1.cin;
+    a.cin_real = c1.cin;
+    a.dil = c1.dil;
+    a.pad = c1.pad;
+    a.slope_in = 0.1f;
+    a.slope_out = slope_out;
+    a.acc_add = acc_add;
+    a.div = div;
+    const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
+    if (prof) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            h->prof_events.emplace_back(e0, e1);
+        }
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+    }
+    hipError_t e = launch_pair_bf16(c1.cin, c1.k, a, s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+        h->prof_used++;
+        h->prof_flops += 2.0 * 2.0 * (double)B * L * c1.cin * c1.cout * c1.k;  // two convolutions
+    }
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused pair launch for %s failed: %s", c1.key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 struct Taps;
 int tap_copy_bf16(const void* src, float* dst, size_t n, hipStream_t s) {
     hipError_t e = launch_bf16_to_f32(src, dst, n, s);
@@ -497,6 +553,19 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             for (int j = 0; j < nk; ++j) {
                 const int base = h->idx_res[i * nk + j];
                 const char* cur = bufX;
+                const bool last_rb = (j == nk - 1);
+                if (h->opt_fuse && h->layers[base].has_pair && h->layers[base + 2].has_pair && h->layers[base + 4].has_pair) {
+                    // fused pairs cannot run in place (a neighbour tile's halo would see updated rows):
+                    // X -> T -> C -> S, with X kept for the other ResBlocks of the stage
+                    rc = run_pair_bf16(h, h->layers[base + 0], cur, nb, (int)L, 1.0f, bufT, 0, 1.f, s);
+                    if (rc) return rc;
+                    rc = run_pair_bf16(h, h->layers[base + 2], bufT, nb, (int)L, 1.0f, bufC, 0, 1.f, s);
+                    if (rc) return rc;
+                    rc = run_pair_bf16(h, h->layers[base + 4], bufC, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
+                                       last_rb ? (float)nk : 1.0f, s);
+                    if (rc) return rc;
+                    continue;
+                }
                 for (int z = 0; z < 3; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
                     const Layer& c2 = h->layers[base + 2 * z + 1];
@@ -506,9 +575,8 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                         rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, 1.0f, cur, bufC, 0, 1.f, s);
                         cur = bufC;
                     } else {
-                        const bool last = (j == nk - 1);
-                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, last ? next_slope : 1.0f, cur, bufS, j > 0 ? 1 : 0,
-                                            last ? (float)nk : 1.0f, s);
+                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, last_rb ? next_slope : 1.0f, cur, bufS, j > 0 ? 1 : 0,
+                                            last_rb ? (float)nk : 1.0f, s);
                     }
                     if (rc) return rc;
                 }
@@ -779,6 +847,18 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
                 bf16_pack(l.w.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
             }
         }
+        for (size_t i = 0; i + 1 < h->layers.size(); ++i) {
+            const Layer& c1 = h->layers[i];
+            if (!c1.has_pair) continue;
+            const Layer& c2 = h->layers[i + 1];
+            const BPackGeom pg = pair_pack_geom(c1.cin, c1.k);
+            const size_t half = bf16_packed_bytes(pg);
+            bf16_pack(c1.w.data(), c1.cin, pg, reinterpret_cast<unsigned short*>(host.data() + c1.off_pw));
+            bf16_pack(c2.w.data(), c2.cin, pg, reinterpret_cast<unsigned short*>(host.data() + c1.off_pw + half));
+            float* pb = reinterpret_cast<float*>(host.data() + c1.off_pb);
+            memcpy(pb, c1.b.data(), c1.cin * sizeof(float));
+            memcpy(pb + c1.cin, c2.b.data(), c1.cin * sizeof(float));
+        }
     }
     for (auto& l : h->layers) {
         if (h->dtype == VTTS_BF16) break;
@@ -905,6 +985,28 @@ VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const flo
                      static_cast<hipStream_t>(stream));
 }
 
+VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_dev, int B, int L, float* y_dev, vtts_stream stream) {
+    if (!h || !key_c1 || !x_dev || !y_dev) return fail(VTTS_ERR_INVALID, "null argument");
+    if (!h->blob) return fail(VTTS_ERR_STATE, "run_pair() before pack()/bind_packed()");
+    if (B <= 0 || L <= 0) return fail(VTTS_ERR_INVALID, "B and L must be positive");
+    Layer* l = find_layer(h, key_c1);
+    if (!l || !l->has_pair) return fail(VTTS_ERR_INVALID, "'%s' is not the first convolution of a fused ResBlock pair (bf16 handles only)", key_c1);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)B * L * l->cin;
+    void *xb = nullptr, *yb = nullptr;
+    HIP_TRY(hipMalloc(&xb, n * 2));
+    HIP_TRY(hipMalloc(&yb, n * 2));
+    int rc = VTTS_OK;
+    if (launch_f32_to_bf16(x_dev, xb, n, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+    if (!rc) rc = run_pair_bf16(h, *l, xb, B, L, 1.0f, yb, 0, 1.f, st);
+    if (!rc && launch_bf16_to_f32(yb, y_dev, n, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(xb);
+    (void)hipFree(yb);
+    if (!rc && e != hipSuccess) rc = fail(VTTS_ERR_HIP, "run_pair failed: %s", hipGetErrorString(e));
+    return rc;
+}
+
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
     if (!strcmp(name, "kernels")) {
@@ -913,6 +1015,8 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "microbatch")) {
         if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
         h->opt_microbatch = value;
+    } else if (!strcmp(name, "fuse")) {
+        h->opt_fuse = value ? 1 : 0;
     } else if (!strcmp(name, "streams")) {
         if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
         h->opt_streams = value;
@@ -934,6 +1038,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "profile")) *value = h->opt_profile;
     else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
     else if (!strcmp(name, "streams")) *value = h->opt_streams;
+    else if (!strcmp(name, "fuse")) *value = h->opt_fuse;
     else if (!strcmp(name, "hop")) *value = h->hop;
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;
     else if (!strcmp(name, "profile_K")) *value = h->prof_K;
@@ -961,4 +1066,7 @@ VTTS_API int vtts_hifigan_profile_read(vtts_hifigan* h, double* resblock_ms, int
     return VTTS_OK;
 }
 
-VTTS_API const char* vtts_hifigan_profile_kernel(const vtts_hifigan* h) { return h ? h->prof_name.c_str() : ""; }
+VTTS_API const char* vtts_hifigan_profile_kernel(const vtts_hifigan* h) {
+    if (!h) return "";
+    return (h->dtype == VTTS_BF16 && h->opt_fuse) ? h->prof_name_pair.c_str() : h->prof_name.c_str();
+}

@@ -29,7 +29,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "vtts_internal.h"
+#include "bf16_common.h"
 
 // timing ablations (never defined in the product build): results are wrong when any is set
 #ifndef VTTS_EXP_NOSTORE
@@ -46,25 +46,6 @@
 #endif
 
 namespace vtts {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __attribute__((address_space(1))) const void* glb_ptr_t;
-
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    f32x2 v = {lo, hi};
-    bf16x2 b = __builtin_convertvector(v, bf16x2);  // v_cvt_pk_bf16_f32 (round-to-nearest-even)
-    return __builtin_bit_cast(unsigned, b);
-}
-__device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ float lrelu_f(float v, float s) { return v >= 0.0f ? v : v * s; }
-__device__ __forceinline__ unsigned lrelu_bf16x2(unsigned u, float s) {
-    return pack_bf16x2(lrelu_f(bf16_lo(u), s), lrelu_f(bf16_hi(u), s));
-}
 
 template <int CINP_, int XC_, int CKC_, int COUTP_, int KS_, int MT_, int NT_, int WM_, int WN_, int TG_, int PA_, bool IN_F32_>
 struct BTile {

@@ -90,6 +90,12 @@ BPackGeom bf16_pack_geom(int cls, int K);
 const char* bf16_kernel_name(int cls, int K);
 size_t bf16_packed_bytes(const BPackGeom& g);
 void bf16_pack(const float* Wc, int cin_real, const BPackGeom& g, unsigned short* out);
+// fused ResBlock1 pair (c1 -> lrelu -> c2 -> + x): kernels_bf16_pair.hip.  a.wp = [c1 slabs][c2 slabs],
+// a.bias = [b1 (C)][b2 (C)], a.x = raw pair input (also the residual), a.dil/a.pad = c1's rate / pad.
+bool pair_bf16_supported(int C, int K, int dil);
+BPackGeom pair_pack_geom(int C, int K);
+hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+const char* pair_kernel_name(int C, int K);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);

@@ -214,6 +214,16 @@ class Generator:
             )
         return y
 
+    def run_pair(self, key_c1: str, x: torch.Tensor) -> torch.Tensor:
+        """bf16 handles: one fused ResBlock pair, ``x`` fp32 ``[B, L, C]`` channels-last -> same shape."""
+        x = x.contiguous()
+        B, L, _ = x.shape
+        y = torch.empty_like(x)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_hifigan_run_pair(self._h, key_c1.encode(), _ptr(x), B, L, _ptr(y), C.c_void_p(stream.cuda_stream)))
+        return y
+
     # ---- dominant-kernel timing (bench.py roofline) ----------------------------------------------
     def profile_read(self, reset: bool = True):
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)
