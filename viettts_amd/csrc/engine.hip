@@ -449,9 +449,11 @@ size_t max_act_elems(const vtts_hifigan* h, int T) {
 
 int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     if (h->opt_microbatch > 0) return (int)std::min<int64_t>(h->opt_microbatch, B);
-    // enough frames per pass that stage 1 (fewest time tiles) still fills 256 CUs; small enough that
-    // the four activation buffers of a pass stay a few hundred MB (Infinity-Cache friendly)
-    int mb = (4096 + T - 1) / T;
+    // Enough frames per pass that every launch is many rounds of workgroups on the 256 CUs: with few
+    // rounds the last, partly filled one costs 10-20 % (measured: bf16 61.6 ms/step at 4096 frames per
+    // pass, 49.9 ms at 65536).  fp32 tiles are 2-4x narrower, so fewer frames reach the same round count.
+    const int frames = (h->dtype == VTTS_BF16) ? 65536 : 16384;
+    int mb = (frames + T - 1) / T;
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
     return mb;

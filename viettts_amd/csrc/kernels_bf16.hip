@@ -300,7 +300,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
 // Two workgroups per CU (<= 80 KiB LDS each) so that one workgroup's HBM phases (X staging, epilogue)
 // overlap the other's MFMA phase.
 //                        CINP XC  CKC COUTP KS  MT   NT  WM WN TG PA  IN_F32
-template <int KS> using BRes256 = BTile<256, 128, 64, 256, KS, 128, 128, 2, 2, 1, (KS - 1) / 2 * 5, false>;
+template <int KS> using BRes256 = BTile<256, 128, 128, 256, KS, 128, 256, 2, 4, 1, (KS - 1) / 2 * 5, false>;  // 8 waves: stage 1 runs un-fused
 template <int KS> using BRes128 = BTile<128, 128, 64, 128, KS, 128, 128, 2, 2, 1, (KS - 1) / 2 * 5, false>;
 template <int KS> using BRes64 = BTile<64, 64, 64, 64, KS, 64, 256, 1, 4, 2, (KS - 1) / 2 * 5, false>;
 template <int KS> using BRes32 = BTile<32, 32, 32, 32, KS, 32, 256, 1, 4, KS, (KS - 1) / 2 * 5, false>;
@@ -353,7 +353,7 @@ BPackGeom bf16_pack_geom(int cls, int K) {
     auto mk = [](int cinp, int ckc, int coutp, int ks, int mt, int tg) { return BPackGeom{cinp, ckc, coutp, ks, mt, tg}; };
     (void)K;
     switch (cls) {
-        case BCLS_RES256: return mk(256, 64, 256, K, 128, 1);
+        case BCLS_RES256: return mk(256, 128, 256, K, 128, 1);
         case BCLS_RES128: return mk(128, 64, 128, K, 128, 1);
         case BCLS_RES64: return mk(64, 64, 64, K, 64, 2);
         case BCLS_RES32: return mk(32, 32, 32, K, 32, K);

@@ -21,6 +21,27 @@
 
 #include "bf16_common.h"
 
+// timing ablations (never defined in the product build): results are wrong when any is set
+#ifndef VTTS_ABL_NOB
+#define VTTS_ABL_NOB 0
+#endif
+#ifndef VTTS_ABL_NOA
+#define VTTS_ABL_NOA 0
+#endif
+#ifndef VTTS_ABL_NODMA
+#define VTTS_ABL_NODMA 0
+#endif
+#ifndef VTTS_ABL_NOBAR
+#define VTTS_ABL_NOBAR 0
+#endif
+#ifndef VTTS_ABL_NOMFMA
+#define VTTS_ABL_NOMFMA 0
+#endif
+// experiment: stream the weight slabs global -> VGPR -> ds_write instead of LDS-DMA
+#ifndef VTTS_SLAB_VIA_REGS
+#define VTTS_SLAB_VIA_REGS 0
+#endif
+
 namespace vtts {
 
 template <int C_, int XC_, int CKC_, int KS_, int N1_, int WM_, int WN_, int TG_>
@@ -99,8 +120,26 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int u0 = wave * 64 + i * THREADS;
-            if (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS)
+            if (!VTTS_ABL_NODMA && (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS))
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + u0 + lane), (lds_ptr_t)(dst + (size_t)i * THREADS * 16), 16, 0, 0);
+        }
+    };
+    uint4 areg[APT];
+    auto load_slab_regs = [&](int s) {
+        const uint4* src = wsl + (size_t)s * T::SLAB_UNITS;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int u = tid + i * THREADS;
+            if (APT * THREADS == T::SLAB_UNITS || u < T::SLAB_UNITS) areg[i] = src[u];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the loads stay here, a whole slab of MFMAs ahead of their use
+    };
+    auto write_slab_regs = [&](int buf) {
+        uint4* dst = reinterpret_cast<uint4*>(ab + buf * T::SLAB_BYTES);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int u = tid + i * THREADS;
+            if (APT * THREADS == T::SLAB_UNITS || u < T::SLAB_UNITS) dst[u] = areg[i];
         }
     };
     // X rows [t0 - H2 - PA1, +ROWSX): LeakyReLU + zero padding in registers, swizzled ds_write_b128
@@ -161,21 +200,29 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
                 if (ks + 1 < KSTEPS) {
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr)
-                        bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + (((slot0 + (ks + 1) * 2) ^ rowswz[nr]) << 4));
+                        if (!VTTS_ABL_NOB) bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + (((slot0 + (ks + 1) * 2) ^ rowswz[nr]) << 4));
+                        else bfn[nr] = bf[nr];
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + ((ks + 1) * MB + mr) * 1024);
+                    for (int mr = 0; mr < MR; ++mr)
+                        if (!VTTS_ABL_NOA) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + ((ks + 1) * MB + mr) * 1024);
+                        else afn[mr] = af[mr];
                 } else if (tj + 1 < ntaps) {
                     set_rows(tj + 1);
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + ((slot0 ^ rowswz[nr]) << 4));
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (!VTTS_ABL_NOB) bfn[nr] = *reinterpret_cast<const bf16x8*>(xt + rowoff[nr] + ((slot0 ^ rowswz[nr]) << 4));
+                        else bfn[nr] = bf[nr];
 #pragma unroll
-                    for (int mr = 0; mr < MR; ++mr) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + (KSTEPS * MB + mr) * 1024);
+                    for (int mr = 0; mr < MR; ++mr)
+                        if (!VTTS_ABL_NOA) afn[mr] = *reinterpret_cast<const bf16x8*>(aslab + (KSTEPS * MB + mr) * 1024);
+                        else afn[mr] = af[mr];
                 }
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
+                        if (!VTTS_ABL_NOMFMA) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
+                        else acc[mr][nr][0] += (float)af[mr][0] * (float)bf[nr][1];
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) af[mr] = afn[mr];
 #pragma unroll
@@ -184,8 +231,14 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
     };
 
-    issue_slab(0, 0);
-    stage_x(0);
+    if (VTTS_SLAB_VIA_REGS) {
+        load_slab_regs(0);
+        stage_x(0);
+        write_slab_regs(0);
+    } else {
+        issue_slab(0, 0);
+        stage_x(0);
+    }
     __syncthreads();
 
     // ---------------- phase 1: xt = c1(lrelu(x)) over N1 rows starting at time t0 - H2 ----------------
@@ -197,12 +250,16 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
         for (int ck = 0; ck < NCK1; ++ck) {
             for (int sl = 0; sl < NSL; ++sl, ++s) {
-                if ((s + 1) < NSTOT) issue_slab(s + 1, (s + 1) & 1);
+                if ((s + 1) < NSTOT) {
+                    if (VTTS_SLAB_VIA_REGS) load_slab_regs(s + 1);
+                    else issue_slab(s + 1, (s + 1) & 1);
+                }
                 const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
                 // column n <-> xt time t0 - H2 + n; tap j reads x time t0 - H2 + n + j*dil - h1 = X row n + j*dil + (PA1 - h1)
                 mma_slab(ab + (s & 1) * T::SLAB_BYTES, ntaps, sl * TG, ck * (CKC / 8) + lh, dil, PA1 - h1,
                          std::integral_constant<int, SPR1>{});
-                __syncthreads();
+                if (VTTS_SLAB_VIA_REGS && (s + 1) < NSTOT) write_slab_regs((s + 1) & 1);
+                if (!VTTS_ABL_NOBAR) __syncthreads();
             }
         }
     }
@@ -243,10 +300,14 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
     for (int ck = 0; ck < NCK2; ++ck) {
         for (int sl = 0; sl < NSL; ++sl, ++s) {
-            if ((s + 1) < NSTOT) issue_slab(s + 1, (s + 1) & 1);
+            if ((s + 1) < NSTOT) {
+                if (VTTS_SLAB_VIA_REGS) load_slab_regs(s + 1);
+                else issue_slab(s + 1, (s + 1) & 1);
+            }
             const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
             mma_slab(ab + (s & 1) * T::SLAB_BYTES, ntaps, sl * TG, ck * (CKC / 8) + lh, 1, 0, std::integral_constant<int, SPR2>{});
-            __syncthreads();
+            if (VTTS_SLAB_VIA_REGS && (s + 1) < NSTOT) write_slab_regs((s + 1) & 1);
+            if (!VTTS_ABL_NOBAR) __syncthreads();
         }
     }
 
@@ -349,7 +410,10 @@ hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
 }
 
 bool pair_bf16_supported(int C, int K, int dil) {
-    return (C == 256 || C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
+    // C = 256 has an instantiation (PRes256) but is not used: all 256 xt channels must sit in one
+    // workgroup's LDS, which caps its tile at 128 columns and doubles the weight stream per output
+    // column — measured 1.5x slower than two un-fused launches (profiles/r01_d_*).
+    return (C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
 }
 
 // packing geometry of ONE of the pair's two convolutions (all C output rows in one m-tile)
