@@ -23,6 +23,8 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v >= 0.0f ? v : v * s; }
+// slope 0.1 < 1: leaky_relu(v) = max(v, 0.1 v) — identical values (v >= 0: v >= 0.1 v; v < 0: 0.1 v > v), one op fewer
+__device__ __forceinline__ float lrelu01(float v) { return fmaxf(v, v * 0.1f); }
 __device__ __forceinline__ unsigned lrelu_bf16x2(unsigned u, float s) {
     return pack_bf16x2(lrelu_f(bf16_lo(u), s), lrelu_f(bf16_hi(u), s));
 }
@@ -30,6 +32,42 @@ __device__ __forceinline__ unsigned lrelu_bf16x2(unsigned u, float s) {
 
 // 16-byte-slot XOR swizzle of a channels-last LDS tile with SPR slots per row: consecutive time rows
 // (the 32 lanes of an MFMA B fragment read) land on distinct slots of the 256-byte bank row.
+// kernel-development builds (-DVTTS_TIMELINE=1, tools/kbench): thread 0 of every workgroup stamps the
+// shader clock at phase boundaries into BConvArgs::dbg[wg * 16 + i]; slot 15 = (XCC_ID << 32) | HW_ID
+#ifndef VTTS_TIMELINE
+#define VTTS_TIMELINE 0
+#endif
+#if VTTS_TIMELINE
+#define VTTS_TL(a, wg, i)                                                                  \
+    do {                                                                                   \
+        if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)(wg) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define VTTS_TL_ID(a, wg)                                                                  \
+    do {                                                                                   \
+        if ((a).dbg && threadIdx.x == 0)                                                   \
+            (a).dbg[(size_t)(wg) * 16 + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | \
+                                              (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); \
+    } while (0)
+#else
+#define VTTS_TL(a, wg, i) do { } while (0)
+#define VTTS_TL_ID(a, wg) do { } while (0)
+#endif
+
+// 16-byte-per-lane LDS-DMA that hipcc does not see (MI355X guide §5.7): a wave that issues
+// __builtin_amdgcn_global_load_lds gets every later ds_read wait as s_waitcnt lgkmcnt(0) instead of a counted one
+// (measured on the fragment pipeline of kernels_bf16_rb.hip).  lds_dst = wave-uniform LDS byte address; lane i's 16
+// bytes land at lds_dst + 16*i.  Completion is the caller's business: a counted s_waitcnt vmcnt, then a barrier.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
+
 template <int SPR>
 __device__ __forceinline__ int swz_of(int row) {
     constexpr int RPB = SPR >= 16 ? 1 : 16 / SPR;

@@ -102,6 +102,9 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
     const int h1 = a.pad;                    // c1's symmetric pad = (K-1)/2 * rate
 
     const uint4* __restrict__ wsl = reinterpret_cast<const uint4*>(a.wp);
+    [[maybe_unused]] const int wg_lin = blockIdx.z * gridDim.x + blockIdx.x;
+    VTTS_TL(a, wg_lin, 0);
+    VTTS_TL_ID(a, wg_lin);
 
     f32x16 acc[MR][NR];
     auto zero_acc = [&]() {
@@ -240,6 +243,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         stage_x(0);
     }
     __syncthreads();
+    VTTS_TL(a, wg_lin, 1);
 
     // ---------------- phase 1: xt = c1(lrelu(x)) over N1 rows starting at time t0 - H2 ----------------
     int s = 0;
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
     }
 
+    VTTS_TL(a, wg_lin, 2);
     // ---------------- epilogue 1: bias, LeakyReLU(0.1), bf16, zero outside [0, L) -> xt tile in LDS ----------------
     // (all waves are past the barrier that ended the last c1 slab: the X tile is dead)
     {
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
     }
     zero_acc();
     __syncthreads();
+    VTTS_TL(a, wg_lin, 3);
 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
     for (int ck = 0; ck < NCK2; ++ck) {
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
     }
 
+    VTTS_TL(a, wg_lin, 4);
     // ---------------- epilogue 2 ----------------
     float* ep = reinterpret_cast<float*>(lds);
     constexpr int EPF = T::EP_PITCH / 4;
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
     }
     __syncthreads();
+    VTTS_TL(a, wg_lin, 5);
 
     constexpr int UPR = C / 8;
     const float s_out = a.slope_out;
@@ -367,6 +375,7 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
         }
         *reinterpret_cast<uint4*>(y + g) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
     }
+    VTTS_TL(a, wg_lin, 6);
 }
 
 // ---- tile table -------------------------------------------------------------------------------------

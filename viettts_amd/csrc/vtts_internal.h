@@ -81,6 +81,7 @@ struct BConvArgs {
     float slope_out;      // LeakyReLU applied to the stored output (the consumer's activation), 1 = none
     int acc_add;          // y = y + v   (MRF accumulate)
     float div;            // then v / div (MRF mean), 1 = none
+    unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE): per-workgroup s_memtime stamps; else unused
 };
 
 struct BPackGeom { int cinp, ckc, coutp, ks, mt, tg; };
@@ -96,6 +97,12 @@ bool pair_bf16_supported(int C, int K, int dil);
 BPackGeom pair_pack_geom(int C, int K);
 hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 const char* pair_kernel_name(int C, int K);
+// second-generation fused pair (kernels_bf16_rb.hip): variant 0 = two 4-wave workgroups per CU, 1 = first-generation geometry
+hipError_t launch_pair2_bf16(int C, int K, int variant, const BConvArgs& a, hipStream_t s);
+BPackGeom pair2_pack_geom(int C, int K, int variant);
+// fused pair with a weight-loader wave and barrier-free main loops (kernels_bf16_rbl.hip): C = 128, 64
+hipError_t launch_pair_lw_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+BPackGeom pair_lw_pack_geom(int C, int K);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
