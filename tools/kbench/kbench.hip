@@ -92,11 +92,9 @@ int main(int argc, char** argv) {
     int dflags = 0, stagger = 0;
     if (argc > 9) stagger = atoi(argv[9]);  // kernels_bf16_rb.hip: start offset (shader cycles) of a CU's second workgroup
     if (argc > 8) dflags = atoi(argv[8]);  // timeline builds of kernels_bf16_rb.hip: experiment switches (results wrong)
-    if (argc > 7) impl = atoi(argv[7]);  // 0 = kernels_bf16_pair.hip, 1/2 = kernels_bf16_rb.hip variant 0/1
+    if (argc > 7) impl = atoi(argv[7]);  // 0 = kernels_bf16_pair.hip (LDS-staged weights), 30 = kernels_bf16_rbg.hip
     printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
-    auto launch = [&](const BConvArgs& aa) {
-        return impl == 0 ? launch_pair_bf16(C, K, aa, 0) : impl == 20 ? launch_pair_lw_bf16(C, K, aa, 0) : launch_pair2_bf16(C, K, impl - 1, aa, 0);
-    };
+    auto launch = [&](const BConvArgs& aa) { return impl == 0 ? launch_pair_lds_bf16(C, K, aa, 0) : launch_pair_g_bf16(C, K, aa, 0); };
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     const size_t n = (size_t)B * L * C;
@@ -107,7 +105,7 @@ int main(int argc, char** argv) {
     for (auto& v : w1) v = bf2f(f2bf(ws * nd(rng)));
     for (auto& v : w2) v = bf2f(f2bf(ws * nd(rng)));
     for (auto& v : bias) v = 0.1f * nd(rng);
-    const BPackGeom g = impl == 0 ? pair_pack_geom(C, K) : impl == 20 ? pair_lw_pack_geom(C, K) : pair2_pack_geom(C, K, impl - 1);
+    const BPackGeom g = impl == 0 ? pair_lds_pack_geom(C, K) : pair_g_pack_geom(C, K);
     const size_t pb = bf16_packed_bytes(g);
     std::vector<unsigned short> wp(pb);  // 2 * pb bytes
     bf16_pack(w1.data(), C, g, wp.data());
@@ -218,13 +216,14 @@ int main(int argc, char** argv) {
             printf("  %-34s %9.0f\n", nm, sm / nwg);
         };
         printf("timeline over %d workgroups (shader-clock ticks, mean per workgroup; thread 0's view):\n", nwg);
-        if (impl == 20) {
+        if (impl == 20 || impl >= 30) {
             seg("stage_x + barrier", 0, 1);
             seg("c1 main loop", 1, 2);
             seg("B2 + epilogue 1 + B3", 2, 3);
             seg("c2 main loop", 3, 4);
             seg("epilogue 2", 4, 6);
             double sp = 0, st = 0;
+            if (impl == 20)
             for (int i = 0; i < nwg; ++i) { sp += (double)h[(size_t)i * 16 + 11]; st += (double)h[(size_t)i * 16 + 12]; }
             printf("  wave 0: failed ready-polls per workgroup %.1f, ticks spent spinning %.0f\n", sp / nwg, st / nwg);
         } else if (impl == 0) {

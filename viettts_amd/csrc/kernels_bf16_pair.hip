@@ -380,9 +380,8 @@ __global__ __launch_bounds__(T::THREADS) void resblock_pair_bf16_k(BConvArgs a) 
 
 // ---- tile table -------------------------------------------------------------------------------------
 //                                      C    XC  CKC  KS  N1  WM WN TG
-template <int KS> using PRes256 = PTile<256, 128, 64, KS, 128, 4, 2, 1>;
-template <int KS> using PRes128 = PTile<128, 128, 128, KS, 256, 2, 4, 1>;
-template <int KS> using PRes64 = PTile<64, 64, 64, KS, 512, 1, 8, (KS < 4 ? KS : 4)>;
+// (the C = 128 / 64 geometries of this generation — 8 waves, weight slabs double-buffered through LDS with one
+// s_barrier per slab — are superseded by kernels_bf16_rbg.hip; C = 32 still runs fastest here)
 template <int KS> using PRes32 = PTile<32, 32, 32, KS, 512, 1, 8, KS>;
 
 template <class T>
@@ -408,38 +407,20 @@ static hipError_t launch_p_ks(const BConvArgs& a, int K, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
-    switch (C) {
-        case 256: return launch_p_ks<PRes256>(a, K, s);
-        case 128: return launch_p_ks<PRes128>(a, K, s);
-        case 64: return launch_p_ks<PRes64>(a, K, s);
-        case 32: return launch_p_ks<PRes32>(a, K, s);
-    }
+hipError_t launch_pair_lds_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
+    if (C == 32) return launch_p_ks<PRes32>(a, K, s);
     return hipErrorInvalidValue;
 }
 
-bool pair_bf16_supported(int C, int K, int dil) {
-    // C = 256 has an instantiation (PRes256) but is not used: all 256 xt channels must sit in one
-    // workgroup's LDS, which caps its tile at 128 columns and doubles the weight stream per output
-    // column — measured 1.5x slower than two un-fused launches (profiles/r01_d_*).
-    return (C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
-}
-
 // packing geometry of ONE of the pair's two convolutions (all C output rows in one m-tile)
-BPackGeom pair_pack_geom(int C, int K) {
-    switch (C) {
-        case 256: return BPackGeom{256, 64, 256, K, 256, 1};
-        case 128: return BPackGeom{128, 128, 128, K, 128, 1};
-        case 64: return BPackGeom{64, 64, 64, K, 64, K < 4 ? K : 4};
-        case 32: return BPackGeom{32, 32, 32, K, 32, K};
-    }
+BPackGeom pair_lds_pack_geom(int C, int K) {
+    if (C == 32) return BPackGeom{32, 32, 32, K, 32, K};
     return BPackGeom{0, 0, 0, 0, 0, 0};
 }
 
-const char* pair_kernel_name(int C, int K) {
+const char* pair_lds_kernel_name(int C, int K) {
     static thread_local char buf[96];
-    const BPackGeom g = pair_pack_geom(C, K);
-    snprintf(buf, sizeof(buf), "resblock_pair_bf16_k<PTile<%d, %d, %d, %d,", C, C < 128 ? C : 128, g.ckc, K);
+    snprintf(buf, sizeof(buf), "resblock_pair_bf16_k<PTile<%d, %d, %d, %d,", C, C, C, K);
     return buf;
 }
 

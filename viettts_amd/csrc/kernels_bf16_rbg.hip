@@ -1,0 +1,381 @@
+// Fused ResBlock1 pair in bf16, weights straight from L2 into registers:   x' = c2(lrelu(c1(lrelu(x)))) + x
+// (vietTTS/hifigan/model.py:45-50).
+//
+// What the per-workgroup timelines of the LDS-staged generations showed (tools/kbench, profiles/r01_e_*): the MFMA
+// main loops run at the matrix-pipe rate only when nothing in them synchronises the workgroup; every scheme that
+// streams the weight slabs through LDS needs such a synchronisation per slab (s_barrier, or ready/done flags that a
+// loader wave cannot serve fast enough) and lost 25-45 % of the loop to it.  This generation has NO shared weight
+// staging at all:
+//   * A operands (weights): host-packed in MFMA A-fragment order, so one global_load_dwordx4 per lane is one whole
+//     fragment (1 KiB per wave, perfectly coalesced, L2/L1-resident: every workgroup reads the same 0.1-0.7 MB).  Each
+//     wave loads the fragments of ITS m-blocks PA k-steps ahead into a register ring.  No LDS, no barrier, no flag.
+//   * B operands (activations): the X tile (later the xt tile) in LDS, staged once per tile as before; each wave reads
+//     its fragments one k-step ahead.
+//   * wave tile 64 x 128 (MR = 2, NR = 4): per 8 MFMAs 2 KiB of A through the vector-memory path (half its 64 B/clk)
+//     and 4 KiB of B through LDS (a quarter of its rate) — half the LDS traffic of the 64 x 64 wave tiles.
+//   * LDS holds only the activation tile (<= 78 KiB), so two 4-wave workgroups share a CU; nothing couples their phases.
+// s_barrier remains at the three tile-level hand-offs (X staged / X dead / xt written).
+#include <stdio.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "bf16_common.h"
+
+namespace vtts {
+
+template <int C_, int KS_, int N1_, int WM_, int WN_, int PA_, int MINWG_>
+struct GTile {
+    static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, PA = PA_, MINWG = MINWG_;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int MR = C / WM / 32, NR = N1 / WN / 32;
+    static constexpr int H2 = (KS - 1) / 2;             // c2 halo (rate 1); c1's is H2 * rate
+    static constexpr int MAXDIL = 5;
+    static constexpr int NT2 = N1 - 2 * H2;             // outputs per workgroup
+    static constexpr int SPR = C / 8, P = C * 2;        // 16-byte slots / bytes per tile row (X and xt tiles alike)
+    static constexpr int ROWSX_MAX = N1 + 2 * H2 * MAXDIL;
+    static constexpr int ROWST = N1 + 2 * H2;           // xt rows incl. the tail only discarded columns read
+    static constexpr int KSTEPS = C / 16;               // k-steps per tap
+    static constexpr int NQT = KS * KSTEPS;             // k-steps per convolution
+    static constexpr int MB = C / 32;
+    static constexpr int RA = PA + 1;                   // A-fragment register ring (slots)
+    static constexpr bool UNROLL_ALL = (KSTEPS % RA) != 0;  // else: loop over taps, KSTEPS steps per iteration
+    static constexpr int XPT = (ROWSX_MAX * SPR + THREADS - 1) / THREADS;
+    static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;  // packed weights of one convolution
+    static_assert(C % (WM * 32) == 0 && N1 % (WN * 32) == 0, "tile/wave mismatch");
+    static_assert(UNROLL_ALL || KSTEPS % RA == 0, "the A ring index must be a compile-time constant in the tap loop");
+    static_assert(SPR == 4 || SPR == 8 || SPR == 16 || SPR == 32, "row pitch 64..512 B");
+    static int lds_bytes(int dil) {
+        const int rowsx = N1 + 2 * H2 * dil;
+        return (rowsx > ROWST ? rowsx : ROWST) * P;
+    }
+    static_assert(ROWSX_MAX * P <= 160 * 1024, "LDS budget");
+};
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) void resblock_pair_g_bf16_k(BConvArgs a) {
+    constexpr int C = T::C, KS = T::KS, N1 = T::N1, WN = T::WN, PA = T::PA, RA = T::RA;
+    constexpr int THREADS = T::THREADS, MR = T::MR, NR = T::NR, H2 = T::H2, NT2 = T::NT2;
+    constexpr int SPR = T::SPR, P = T::P, KSTEPS = T::KSTEPS, NQT = T::NQT, MB = T::MB, XPT = T::XPT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* xt = lds;  // X tile, later the xt tile
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int t0 = blockIdx.x * NT2;         // first output time step of this workgroup
+    const int b = blockIdx.z;
+    const int L = a.L;
+    const int dil = a.dil;
+    const int h1 = H2 * dil;                 // c1's symmetric pad (model.py:8-10)
+    const int rowsx = N1 + 2 * h1;           // X rows: times t0 - H2 - h1 ... t0 - H2 - h1 + rowsx - 1
+    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * L * C;
+    [[maybe_unused]] const int wg_lin = blockIdx.z * gridDim.x + blockIdx.x;
+    VTTS_TL_ID(a, wg_lin);
+    VTTS_TL(a, wg_lin, 0);
+
+    // Accumulators start from the bias (row = channel 32*mr + 8*rq + 4*lh + i of this wave's m-block, r = 4*rq + i)
+    f32x16 acc[MR][NR];
+    auto init_acc = [&](const float* __restrict__ bias) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias + wm * (C / T::WM) + mr * 32 + 8 * rq + 4 * lh);
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    acc[mr][nr][4 * rq + 0] = bv.x;
+                    acc[mr][nr][4 * rq + 1] = bv.y;
+                    acc[mr][nr][4 * rq + 2] = bv.z;
+                    acc[mr][nr][4 * rq + 3] = bv.w;
+                }
+            }
+    };
+
+    // ---------------- X tile: LeakyReLU + zero padding in registers, swizzled ds_write_b128 ----------------
+    {
+        uint4 v[XPT];
+        bool okx[XPT];
+        const int nunits = rowsx * SPR;
+        const int tx0 = t0 - H2 - h1;
+        // unconditional loads from clamped addresses, masked afterwards: a load under a per-element branch makes
+        // hipcc wait for each one before issuing the next
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int u = tid + i * THREADS;
+            const int row = u / SPR, c = u % SPR;
+            const int t = tx0 + row;
+            okx[i] = u < nunits && t >= 0 && t < L;
+            const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+            v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + c * 8);
+        }
+        auto act2 = [](unsigned u) { return pack_bf16x2(lrelu01(bf16_lo(u)), lrelu01(bf16_hi(u))); };  // LRELU_SLOPE, model.py:5,46
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            if (!okx[i]) v[i] = make_uint4(0u, 0u, 0u, 0u);
+            v[i].x = act2(v[i].x);
+            v[i].y = act2(v[i].y);
+            v[i].z = act2(v[i].z);
+            v[i].w = act2(v[i].w);
+        }
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int u = tid + i * THREADS;
+            const int row = u / SPR, c = u % SPR;
+            if (u < nunits) *reinterpret_cast<uint4*>(xt + row * P + ((c ^ swz_of<SPR>(row)) << 4)) = v[i];
+        }
+    }
+    init_acc(a.bias);
+    __syncthreads();  // B1: X tile staged
+    VTTS_TL(a, wg_lin, 1);
+
+    // ---- one convolution over the LDS tile: acc += W (*) tile, k-step q = tap * KSTEPS + ks -------------------------
+    // A fragment (q, mr): 16 bytes per lane at  wconv + ((q*MB + wm*MR + mr)*64 + lane)*16   (bf16_pack order)
+    // B fragment (q, nr): tile row  n + tap*dl  (n = this lane's output column), 16-byte slot 2*ks + lh of that row
+    const int rowbase0 = wn * (N1 / WN) + l31;
+    auto conv_phase = [&](const unsigned char* __restrict__ wconv, int dl) {
+        const uint4* __restrict__ aptr = reinterpret_cast<const uint4*>(wconv) + (size_t)(wm * MR) * 64 + lane;
+        bf16x8 af[RA][MR], bf[2][NR];
+        auto load_a = [&](int q, int slot) {
+            const int qc = q < NQT ? q : NQT - 1;  // look-ahead past the end re-reads the last step (stays inside the blob)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+                af[slot][mr] = __builtin_bit_cast(bf16x8, aptr[(size_t)(qc * MB + mr) * 64]);
+        };
+        auto load_b = [&](int tap, int ks, int par) {
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int row = rowbase0 + tap * dl + nr * 32;
+                bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + row * P + (((ks * 2 + lh) ^ swz_of<SPR>(row)) << 4));
+            }
+        };
+        auto mfma_step = [&](int slot, int par) {
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][mr], bf[par][nr], acc[mr][nr], 0, 0, 0);
+        };
+        // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers)
+        auto pin_step = [&](bool has_b) {
+            __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);       // VMEM reads: A fragments of step q + PA
+            if (has_b) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);  // DS reads: B fragments of step q + 1
+            __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);  // MFMAs of step q
+        };
+#pragma unroll
+        for (int q = 0; q < PA; ++q) load_a(q, q % RA);
+        load_b(0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, MR * PA, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+        if constexpr (T::UNROLL_ALL) {
+#pragma unroll
+            for (int q = 0; q < NQT; ++q) {
+                load_a(q + PA, (q + PA) % RA);
+                if (q + 1 < NQT) load_b((q + 1) / KSTEPS, (q + 1) % KSTEPS, (q + 1) & 1);
+                mfma_step(q % RA, q & 1);
+                pin_step(q + 1 < NQT);
+            }
+        } else {
+            static_assert(T::UNROLL_ALL || KSTEPS % 2 == 0, "B parity");
+#pragma nounroll
+            for (int tap = 0; tap < KS; ++tap) {
+#pragma unroll
+                for (int ks = 0; ks < KSTEPS; ++ks) {
+                    const int q = tap * KSTEPS + ks;
+                    load_a(q + PA, (ks + PA) % RA);
+                    if (ks + 1 < KSTEPS) load_b(tap, ks + 1, (ks + 1) & 1);
+                    else load_b(tap + 1 < KS ? tap + 1 : tap, 0, 0);
+                    mfma_step(ks % RA, ks & 1);
+                    pin_step(true);
+                }
+            }
+        }
+    };
+
+    // ---------------- phase 1: xt = c1(lrelu(x)); column n <-> xt time t0 - H2 + n; tap j reads X row n + j*dil ----------------
+    conv_phase(static_cast<const unsigned char*>(a.wp), dil);
+    VTTS_TL(a, wg_lin, 2);
+    __syncthreads();  // B2: every wave is done reading the X tile
+
+    // A lane's accumulators for one 32x32 block: column (time) l31, rows (channels) 8*rq + 4*lh + i, r = 4*rq + i.
+    // (lo, hi) of two packed dwords: after swapping across the wave halves, lh = 0 owns channels 16p .. 16p+7 and
+    // lh = 1 owns 16p+8 .. 16p+15 of rq pair p, as [P'0 P'1 Q'0 Q'1].
+    auto swap_pair = [](unsigned& pd, unsigned& qd) {
+        auto r = __builtin_amdgcn_permlane32_swap(pd, qd, false, false);
+        pd = r[0];
+        qd = r[1];
+    };
+
+    // ---------------- epilogue 1: LeakyReLU(0.1), bf16, zero outside [0, L) -> xt tile in LDS ----------------
+    {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cb = wm * (C / T::WM) + mr * 32 + 16 * p;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int row = wn * (N1 / WN) + nr * 32 + l31;
+                    const int tt = t0 - H2 + row;
+                    const bool ok = tt >= 0 && tt < L;
+                    const int r0 = 8 * p;
+                    unsigned p0 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 0]), lrelu01(acc[mr][nr][r0 + 1]));
+                    unsigned p1 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 2]), lrelu01(acc[mr][nr][r0 + 3]));
+                    unsigned q0 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 4]), lrelu01(acc[mr][nr][r0 + 5]));
+                    unsigned q1 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 6]), lrelu01(acc[mr][nr][r0 + 7]));
+                    if (!ok) p0 = p1 = q0 = q1 = 0u;  // c2's own zero padding applies to xt
+                    swap_pair(p0, q0);
+                    swap_pair(p1, q1);
+                    const int slot = (cb >> 3) + lh;
+                    *reinterpret_cast<uint4*>(xt + row * P + ((slot ^ swz_of<SPR>(row)) << 4)) = make_uint4(p0, p1, q0, q1);
+                }
+            }
+        }
+        // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
+        for (int u = tid; u < 2 * H2 * SPR; u += THREADS) {
+            const int row = N1 + u / SPR, c = u % SPR;
+            *reinterpret_cast<uint4*>(xt + row * P + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    init_acc(a.bias + C);
+    __syncthreads();  // B3: xt tile written
+    VTTS_TL(a, wg_lin, 3);
+
+    // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
+    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1);
+    VTTS_TL(a, wg_lin, 4);
+
+    // ---------------- epilogue 2: + x [MRF accumulate / mean] [consumer's LeakyReLU] -> bf16, 16-byte stores ----------------
+    {
+        const float s_out = a.slope_out;
+        const float dv = a.div;
+        unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * L * C;
+        // rows of a [B][L][C] tensor in the swapped accumulator layout: all requests first, one wait
+        auto add_rows = [&](const unsigned short* __restrict__ src) {
+            uint4 rv[MR][2][NR];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int t = t0 + wn * (N1 / WN) + nr * 32 + l31;
+                        const int tc = t < L ? t : L - 1;  // rows past the end are never stored: any in-bounds address will do
+                        rv[mr][p][nr] = *reinterpret_cast<const uint4*>(src + (size_t)tc * C + wm * (C / T::WM) + mr * 32 + 16 * p + 8 * lh);
+                    }
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        uint4 r = rv[mr][p][nr];
+                        swap_pair(r.x, r.z);  // un-swap the chunk into the accumulator layout
+                        swap_pair(r.y, r.w);
+                        const int r0 = 8 * p;
+                        acc[mr][nr][r0 + 0] = bf16_lo(r.x) + acc[mr][nr][r0 + 0]; acc[mr][nr][r0 + 1] = bf16_hi(r.x) + acc[mr][nr][r0 + 1];
+                        acc[mr][nr][r0 + 2] = bf16_lo(r.y) + acc[mr][nr][r0 + 2]; acc[mr][nr][r0 + 3] = bf16_hi(r.y) + acc[mr][nr][r0 + 3];
+                        acc[mr][nr][r0 + 4] = bf16_lo(r.z) + acc[mr][nr][r0 + 4]; acc[mr][nr][r0 + 5] = bf16_hi(r.z) + acc[mr][nr][r0 + 5];
+                        acc[mr][nr][r0 + 6] = bf16_lo(r.w) + acc[mr][nr][r0 + 6]; acc[mr][nr][r0 + 7] = bf16_hi(r.w) + acc[mr][nr][r0 + 7];
+                    }
+        };
+        add_rows(xg);                                                       // x = xt + x        (model.py:50)
+        if (a.acc_add != 0) add_rows(yg);                                   // xs += rb(x)       (model.py:118-120)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int cb = wm * (C / T::WM) + mr * 32 + 16 * p;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    const int row = wn * (N1 / WN) + nr * 32 + l31;
+                    const int t = t0 + row;
+                    const bool ok = row < NT2 && t < L;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = acc[mr][nr][8 * p + e];
+                    if (dv != 1.0f) {  // x = xs / num_kernels  (model.py:121)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] / dv;
+                    }
+                    if (s_out != 1.0f) {  // the (only) consumer's LeakyReLU, applied once by the producer
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = lrelu_f(v[e], s_out);
+                    }
+                    unsigned p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+                    unsigned q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                    swap_pair(p0, q0);
+                    swap_pair(p1, q1);
+                    if (ok) *reinterpret_cast<uint4*>(yg + (size_t)t * C + cb + 8 * lh) = make_uint4(p0, p1, q0, q1);
+                }
+            }
+        }
+    }
+    VTTS_TL(a, wg_lin, 6);
+}
+
+// ---- tile table -------------------------------------------------------------------------------------
+//                                       C   KS   N1  WM WN PA MINWG
+template <int KS> using G128 = GTile<128, KS, 256, 2, 2, 3, 2>;
+template <int KS> using G64 = GTile<64, KS, 512, 1, 4, 3, 2>;
+template <int KS> using G32 = GTile<32, KS, 512, 1, 4, 3, 2>;
+template <class T>
+static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_g_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           T::lds_bytes(T::MAXDIL));
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
+    dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
+    hipLaunchKernelGGL(resblock_pair_g_bf16_k<T>, grid, dim3(T::THREADS), T::lds_bytes(a.dil), s, a);
+    return hipGetLastError();
+}
+
+template <template <int> class TT>
+static hipError_t launch_g_ks(const BConvArgs& a, int K, hipStream_t s) {
+    switch (K) {
+        case 3: return launch_g<TT<3>>(a, s);
+        case 7: return launch_g<TT<7>>(a, s);
+        case 11: return launch_g<TT<11>>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
+    switch (C) {
+        case 128: return launch_g_ks<G128>(a, K, s);
+        case 64: return launch_g_ks<G64>(a, K, s);
+        case 32: return launch_g_ks<G32>(a, K, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+// one convolution = [q = tap*KSTEPS + ks][mblk][lane][8] bf16: bf16_pack with (ckc = C, tg = 1, mt = C)
+BPackGeom pair_g_pack_geom(int C, int K) { return BPackGeom{C, C, C, K, C, 1}; }
+
+const char* pair_g_kernel_name(int C, int K) {
+    static thread_local char buf[96];
+    snprintf(buf, sizeof(buf), "resblock_pair_g_bf16_k<GTile<%d, %d,", C, K);
+    return buf;
+}
+
+// ---- the fused-pair entry points the engine uses: which generation runs which channel count ----------------------
+bool pair_bf16_supported(int C, int K, int dil) {
+    return (C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
+}
+static bool pair_uses_g(int C) { return C == 128 || C == 64; }  // measured per class with tools/kbench (profiles/r01_e_*)
+BPackGeom pair_pack_geom(int C, int K) { return pair_uses_g(C) ? pair_g_pack_geom(C, K) : pair_lds_pack_geom(C, K); }
+hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
+    return pair_uses_g(C) ? launch_pair_g_bf16(C, K, a, s) : launch_pair_lds_bf16(C, K, a, s);
+}
+const char* pair_kernel_name(int C, int K) { return pair_uses_g(C) ? pair_g_kernel_name(C, K) : pair_lds_kernel_name(C, K); }
+
+}  // namespace vtts

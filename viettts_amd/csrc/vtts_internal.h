@@ -97,12 +97,15 @@ bool pair_bf16_supported(int C, int K, int dil);
 BPackGeom pair_pack_geom(int C, int K);
 hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 const char* pair_kernel_name(int C, int K);
-// second-generation fused pair (kernels_bf16_rb.hip): variant 0 = two 4-wave workgroups per CU, 1 = first-generation geometry
-hipError_t launch_pair2_bf16(int C, int K, int variant, const BConvArgs& a, hipStream_t s);
-BPackGeom pair2_pack_geom(int C, int K, int variant);
-// fused pair with a weight-loader wave and barrier-free main loops (kernels_bf16_rbl.hip): C = 128, 64
-hipError_t launch_pair_lw_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
-BPackGeom pair_lw_pack_geom(int C, int K);
+// the two generations behind those entry points:
+//   kernels_bf16_rbg.hip   weights straight from L2 into register rings, no workgroup sync in the main loops (C = 128, 64)
+//   kernels_bf16_pair.hip  weight slabs double-buffered through LDS, one s_barrier per slab (C = 32)
+hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+BPackGeom pair_g_pack_geom(int C, int K);
+const char* pair_g_kernel_name(int C, int K);
+hipError_t launch_pair_lds_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+BPackGeom pair_lds_pack_geom(int C, int K);
+const char* pair_lds_kernel_name(int C, int K);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
