@@ -76,8 +76,7 @@ def test_resblock_conv_kat_bf16(gen, v1_params, dev, spec):
 
 def _pair_cases():
     by = {s.key: s for s in conv_specs(V1)}
-    # stage 1 (C = 256) runs un-fused (kernels_bf16_pair.hip::pair_bf16_supported explains why)
-    return [(s, by[s.key.replace("convs1_", "convs2_")]) for s in _res_conv_cases() if "convs1_" in s.key and s.cin != 256]
+    return [(s, by[s.key.replace("convs1_", "convs2_")]) for s in _res_conv_cases() if "convs1_" in s.key]
 
 
 @pytest.mark.parametrize("pair", _pair_cases(), ids=lambda p: f"C{p[0].cin}k{p[0].k}d{p[0].dilation}")
@@ -101,11 +100,12 @@ def test_fused_pair_kat_bf16(gen, v1_params, dev, pair):
     assert err <= 2.0 ** -7 * np.abs(ref).max(), (err, np.abs(ref).max())
 
 
-def test_fused_pair_rejects_stage1(gen, dev):
+def test_fused_pair_rejects_non_pair_keys(gen, dev):
     from viettts_amd import _lib
 
-    with pytest.raises(_lib.VttsError):
-        gen.run_pair("generator/~/res_block1_0/~/convs1_0", torch.zeros((1, 64, 256), device=dev))
+    for key in ("generator/~/res_block1_0/~/convs2_0", "generator/~/ups_0", "generator/~/nope"):
+        with pytest.raises(_lib.VttsError):
+            gen.run_pair(key, torch.zeros((1, 64, 256), device=dev))
 
 
 @pytest.mark.parametrize("i", [0, 1, 2, 3])

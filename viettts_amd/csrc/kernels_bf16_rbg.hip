@@ -14,6 +14,7 @@
 //   * wave tile 64 x 128 (MR = 2, NR = 4): per 8 MFMAs 2 KiB of A through the vector-memory path (half its 64 B/clk)
 //     and 4 KiB of B through LDS (a quarter of its rate) — half the LDS traffic of the 64 x 64 wave tiles.
 //   * LDS holds only the activation tile (<= 78 KiB), so two 4-wave workgroups share a CU; nothing couples their phases.
+//     C = 256: 128-column tiles, the X tile staged 128 input channels at a time (2 x 45 KiB), the xt tile 69 KiB.
 // s_barrier remains at the three tile-level hand-offs (X staged / X dead / xt written).
 #include <stdio.h>
 #include <string.h>
@@ -24,39 +25,44 @@
 
 namespace vtts {
 
-template <int C_, int KS_, int N1_, int WM_, int WN_, int PA_, int MINWG_>
+template <int C_, int KS_, int N1_, int WM_, int WN_, int PA_, int MINWG_, int XC_ = C_>
 struct GTile {
     static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, PA = PA_, MINWG = MINWG_;
+    static constexpr int XC = XC_, NXC = C / XC;        // the X tile is staged XC input channels at a time (C = 256: 2 x 128)
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int MR = C / WM / 32, NR = N1 / WN / 32;
     static constexpr int H2 = (KS - 1) / 2;             // c2 halo (rate 1); c1's is H2 * rate
     static constexpr int MAXDIL = 5;
     static constexpr int NT2 = N1 - 2 * H2;             // outputs per workgroup
-    static constexpr int SPR = C / 8, P = C * 2;        // 16-byte slots / bytes per tile row (X and xt tiles alike)
+    static constexpr int SPR1 = XC / 8, P1 = XC * 2;    // X tile (one channel chunk): 16-byte slots / bytes per row
+    static constexpr int SPR2 = C / 8, P2 = C * 2;      // xt tile (all channels)
     static constexpr int ROWSX_MAX = N1 + 2 * H2 * MAXDIL;
     static constexpr int ROWST = N1 + 2 * H2;           // xt rows incl. the tail only discarded columns read
     static constexpr int KSTEPS = C / 16;               // k-steps per tap
+    static constexpr int KSX = XC / 16;                 // ... of one X channel chunk
     static constexpr int NQT = KS * KSTEPS;             // k-steps per convolution
     static constexpr int MB = C / 32;
     static constexpr int RA = PA + 1;                   // A-fragment register ring (slots)
-    static constexpr bool UNROLL_ALL = (KSTEPS % RA) != 0;  // else: loop over taps, KSTEPS steps per iteration
-    static constexpr int XPT = (ROWSX_MAX * SPR + THREADS - 1) / THREADS;
+    static constexpr bool UNROLL_ALL = (KSX % RA) != 0;  // else: loop over taps, one tap's k-steps per iteration
+    static constexpr int XPT = (ROWSX_MAX * SPR1 + THREADS - 1) / THREADS;
     static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;  // packed weights of one convolution
     static_assert(C % (WM * 32) == 0 && N1 % (WN * 32) == 0, "tile/wave mismatch");
-    static_assert(UNROLL_ALL || KSTEPS % RA == 0, "the A ring index must be a compile-time constant in the tap loop");
-    static_assert(SPR == 4 || SPR == 8 || SPR == 16 || SPR == 32, "row pitch 64..512 B");
+    static_assert(C % XC == 0 && (NXC == 1 || !UNROLL_ALL), "channel chunking");
+    static_assert(SPR1 == 4 || SPR1 == 8 || SPR1 == 16, "X row pitch 64..256 B");
+    static_assert(SPR2 == 4 || SPR2 == 8 || SPR2 == 16 || SPR2 == 32, "xt row pitch 64..512 B");
     static int lds_bytes(int dil) {
-        const int rowsx = N1 + 2 * H2 * dil;
-        return (rowsx > ROWST ? rowsx : ROWST) * P;
+        const int bx = (N1 + 2 * H2 * dil) * P1, bt = ROWST * P2;
+        return bx > bt ? bx : bt;
     }
-    static_assert(ROWSX_MAX * P <= 160 * 1024, "LDS budget");
+    static_assert(ROWSX_MAX * P1 <= 160 * 1024 && ROWST * P2 <= 160 * 1024, "LDS budget");
 };
 
 template <class T>
 __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) void resblock_pair_g_bf16_k(BConvArgs a) {
     constexpr int C = T::C, KS = T::KS, N1 = T::N1, WN = T::WN, PA = T::PA, RA = T::RA;
     constexpr int THREADS = T::THREADS, MR = T::MR, NR = T::NR, H2 = T::H2, NT2 = T::NT2;
-    constexpr int SPR = T::SPR, P = T::P, KSTEPS = T::KSTEPS, NQT = T::NQT, MB = T::MB, XPT = T::XPT;
+    constexpr int SPR1 = T::SPR1, P1 = T::P1, SPR2 = T::SPR2, P2 = T::P2, XC = T::XC, NXC = T::NXC, KSX = T::KSX;
+    constexpr int KSTEPS = T::KSTEPS, NQT = T::NQT, MB = T::MB, XPT = T::XPT;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* xt = lds;  // X tile, later the xt tile
@@ -97,61 +103,71 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             }
     };
 
-    // ---------------- X tile: LeakyReLU + zero padding in registers, swizzled ds_write_b128 ----------------
-    {
-        uint4 v[XPT];
-        bool okx[XPT];
-        const int nunits = rowsx * SPR;
+    // ---------------- X tile (channel chunk xc): LeakyReLU + zero padding in registers, swizzled ds_write_b128 ----------------
+    // XB = loads in flight per thread: all of them for the first chunk (nothing else is live yet), a few at a time for
+    // a later chunk (the accumulators are live: 128 VGPRs)
+    auto stage_x = [&](int xc, auto xb_tag) {
+        constexpr int XB = decltype(xb_tag)::value;
+        const int nunits = rowsx * SPR1;
         const int tx0 = t0 - H2 - h1;
-        // unconditional loads from clamped addresses, masked afterwards: a load under a per-element branch makes
-        // hipcc wait for each one before issuing the next
-#pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int u = tid + i * THREADS;
-            const int row = u / SPR, c = u % SPR;
-            const int t = tx0 + row;
-            okx[i] = u < nunits && t >= 0 && t < L;
-            const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-            v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + c * 8);
-        }
         auto act2 = [](unsigned u) { return pack_bf16x2(lrelu01(bf16_lo(u)), lrelu01(bf16_hi(u))); };  // LRELU_SLOPE, model.py:5,46
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            if (!okx[i]) v[i] = make_uint4(0u, 0u, 0u, 0u);
-            v[i].x = act2(v[i].x);
-            v[i].y = act2(v[i].y);
-            v[i].z = act2(v[i].z);
-            v[i].w = act2(v[i].w);
-        }
+        for (int i0 = 0; i0 < XPT; i0 += XB) {
+            uint4 v[XB];
+            bool okx[XB];
+            // unconditional loads from clamped addresses, masked afterwards: a load under a per-element branch makes
+            // hipcc wait for each one before issuing the next
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int u = tid + i * THREADS;
-            const int row = u / SPR, c = u % SPR;
-            if (u < nunits) *reinterpret_cast<uint4*>(xt + row * P + ((c ^ swz_of<SPR>(row)) << 4)) = v[i];
+            for (int i = 0; i < XB; ++i) {
+                const int u = tid + (i0 + i) * THREADS;
+                const int row = u / SPR1, c = u % SPR1;
+                const int t = tx0 + row;
+                okx[i] = i0 + i < XPT && u < nunits && t >= 0 && t < L;
+                const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+                v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + xc * XC + c * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                if (!okx[i]) v[i] = make_uint4(0u, 0u, 0u, 0u);
+                v[i].x = act2(v[i].x);
+                v[i].y = act2(v[i].y);
+                v[i].z = act2(v[i].z);
+                v[i].w = act2(v[i].w);
+            }
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                const int u = tid + (i0 + i) * THREADS;
+                const int row = u / SPR1, c = u % SPR1;
+                if (i0 + i < XPT && u < nunits) *reinterpret_cast<uint4*>(xt + row * P1 + ((c ^ swz_of<SPR1>(row)) << 4)) = v[i];
+            }
         }
-    }
+    };
+    stage_x(0, std::integral_constant<int, XPT>{});
     init_acc(a.bias);
     __syncthreads();  // B1: X tile staged
     VTTS_TL(a, wg_lin, 1);
 
-    // ---- one convolution over the LDS tile: acc += W (*) tile, k-step q = tap * KSTEPS + ks -------------------------
-    // A fragment (q, mr): 16 bytes per lane at  wconv + ((q*MB + wm*MR + mr)*64 + lane)*16   (bf16_pack order)
-    // B fragment (q, nr): tile row  n + tap*dl  (n = this lane's output column), 16-byte slot 2*ks + lh of that row
+    // ---- one convolution pass over the LDS tile: acc += W[:, chunk] (*) tile -----------------------------------------
+    // The tile holds NKS k-steps (16 channels each) per row, channels 16*ks0 .. of the convolution's input.
+    // A fragment (tap, ks, mr): 16 bytes per lane at  wconv + (((tap*KSTEPS + ks0 + ks)*MB + wm*MR + mr)*64 + lane)*16
+    // B fragment (tap, ks, nr): tile row  n + tap*dl  (n = this lane's output column), 16-byte slot 2*ks + lh of that row
     const int rowbase0 = wn * (N1 / WN) + l31;
-    auto conv_phase = [&](const unsigned char* __restrict__ wconv, int dl) {
-        const uint4* __restrict__ aptr = reinterpret_cast<const uint4*>(wconv) + (size_t)(wm * MR) * 64 + lane;
+    auto conv_phase = [&](const unsigned char* __restrict__ wconv, int dl, auto sprb_tag, auto nks_tag, int ks0) {
+        constexpr int SPRB = decltype(sprb_tag)::value, PB = SPRB * 16, NKS = decltype(nks_tag)::value;
+        constexpr int NSTEPS = KS * NKS;
+        const uint4* __restrict__ aptr = reinterpret_cast<const uint4*>(wconv) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
         bf16x8 af[RA][MR], bf[2][NR];
-        auto load_a = [&](int q, int slot) {
-            const int qc = q < NQT ? q : NQT - 1;  // look-ahead past the end re-reads the last step (stays inside the blob)
+        auto load_a = [&](int tap, int ks, int slot) {  // (tap, ks) may run past the end: re-read the last step (stays inside the blob)
+            const int tc = tap < KS ? tap : KS - 1;
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
-                af[slot][mr] = __builtin_bit_cast(bf16x8, aptr[(size_t)(qc * MB + mr) * 64]);
+                af[slot][mr] = __builtin_bit_cast(bf16x8, aptr[(size_t)((tc * KSTEPS + ks) * MB + mr) * 64]);
         };
         auto load_b = [&](int tap, int ks, int par) {
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int row = rowbase0 + tap * dl + nr * 32;
-                bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + row * P + (((ks * 2 + lh) ^ swz_of<SPR>(row)) << 4));
+                bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + row * PB + (((ks * 2 + lh) ^ swz_of<SPRB>(row)) << 4));
             }
         };
         auto mfma_step = [&](int slot, int par) {
@@ -163,34 +179,37 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         };
         // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers)
         auto pin_step = [&](bool has_b) {
-            __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);       // VMEM reads: A fragments of step q + PA
-            if (has_b) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);  // DS reads: B fragments of step q + 1
-            __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);  // MFMAs of step q
+            __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);       // VMEM reads: A fragments PA steps ahead
+            if (has_b) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);  // DS reads: B fragments of the next step
+            __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);  // MFMAs of this step
         };
+        static_assert(T::UNROLL_ALL || PA <= NKS, "look-ahead within two taps");
 #pragma unroll
-        for (int q = 0; q < PA; ++q) load_a(q, q % RA);
+        for (int s = 0; s < PA; ++s) load_a(s / NKS, s % NKS, s % RA);
         load_b(0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, MR * PA, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
         if constexpr (T::UNROLL_ALL) {
 #pragma unroll
-            for (int q = 0; q < NQT; ++q) {
-                load_a(q + PA, (q + PA) % RA);
-                if (q + 1 < NQT) load_b((q + 1) / KSTEPS, (q + 1) % KSTEPS, (q + 1) & 1);
-                mfma_step(q % RA, q & 1);
-                pin_step(q + 1 < NQT);
+            for (int s = 0; s < NSTEPS; ++s) {
+                load_a((s + PA) / NKS, (s + PA) % NKS, (s + PA) % RA);
+                if (s + 1 < NSTEPS) load_b((s + 1) / NKS, (s + 1) % NKS, (s + 1) & 1);
+                mfma_step(s % RA, s & 1);
+                pin_step(s + 1 < NSTEPS);
             }
         } else {
-            static_assert(T::UNROLL_ALL || KSTEPS % 2 == 0, "B parity");
+            // rolled loop over blocks of UB k-steps (flat step index s = tap*NKS + ks): the ring slot and the B parity
+            // of a step depend only on its position in the block
+            constexpr int UB = NKS < 8 ? NKS : 8;
+            static_assert(T::UNROLL_ALL || (UB % RA == 0 && UB % 2 == 0 && NKS % UB == 0), "ring slot / B parity must be compile-time in the block loop");
 #pragma nounroll
-            for (int tap = 0; tap < KS; ++tap) {
+            for (int s0 = 0; s0 < NSTEPS; s0 += UB) {
 #pragma unroll
-                for (int ks = 0; ks < KSTEPS; ++ks) {
-                    const int q = tap * KSTEPS + ks;
-                    load_a(q + PA, (ks + PA) % RA);
-                    if (ks + 1 < KSTEPS) load_b(tap, ks + 1, (ks + 1) & 1);
-                    else load_b(tap + 1 < KS ? tap + 1 : tap, 0, 0);
-                    mfma_step(ks % RA, ks & 1);
+                for (int i = 0; i < UB; ++i) {
+                    const int sa = s0 + i + PA, sb = s0 + i + 1;
+                    load_a(sa / NKS, sa % NKS, (i + PA) % RA);
+                    load_b(sb < NSTEPS ? sb / NKS : KS - 1, sb < NSTEPS ? sb % NKS : 0, (i + 1) & 1);
+                    mfma_step(i % RA, i & 1);
                     pin_step(true);
                 }
             }
@@ -198,7 +217,15 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     };
 
     // ---------------- phase 1: xt = c1(lrelu(x)); column n <-> xt time t0 - H2 + n; tap j reads X row n + j*dil ----------------
-    conv_phase(static_cast<const unsigned char*>(a.wp), dil);
+#pragma unroll
+    for (int xc = 0; xc < NXC; ++xc) {
+        if (xc > 0) {
+            __syncthreads();  // every wave is done reading the previous channel chunk
+            stage_x(xc, std::integral_constant<int, 4>{});
+            __syncthreads();
+        }
+        conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, xc * KSX);
+    }
     VTTS_TL(a, wg_lin, 2);
     __syncthreads();  // B2: every wave is done reading the X tile
 
@@ -232,14 +259,14 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     swap_pair(p0, q0);
                     swap_pair(p1, q1);
                     const int slot = (cb >> 3) + lh;
-                    *reinterpret_cast<uint4*>(xt + row * P + ((slot ^ swz_of<SPR>(row)) << 4)) = make_uint4(p0, p1, q0, q1);
+                    *reinterpret_cast<uint4*>(xt + row * P2 + ((slot ^ swz_of<SPR2>(row)) << 4)) = make_uint4(p0, p1, q0, q1);
                 }
             }
         }
         // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
-        for (int u = tid; u < 2 * H2 * SPR; u += THREADS) {
-            const int row = N1 + u / SPR, c = u % SPR;
-            *reinterpret_cast<uint4*>(xt + row * P + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+        for (int u = tid; u < 2 * H2 * SPR2; u += THREADS) {
+            const int row = N1 + u / SPR2, c = u % SPR2;
+            *reinterpret_cast<uint4*>(xt + row * P2 + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     init_acc(a.bias + C);
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     VTTS_TL(a, wg_lin, 3);
 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
-    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1);
+    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0);
     VTTS_TL(a, wg_lin, 4);
 
     // ---------------- epilogue 2: + x [MRF accumulate / mean] [consumer's LeakyReLU] -> bf16, 16-byte stores ----------------
@@ -324,6 +351,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 template <int KS> using G128 = GTile<128, KS, 256, 2, 2, 3, 2>;
 template <int KS> using G64 = GTile<64, KS, 512, 1, 4, 3, 2>;
 template <int KS> using G32 = GTile<32, KS, 512, 1, 4, 3, 2>;
+template <int KS> using G256 = GTile<256, KS, 128, 4, 1, 3, 2, 128>;
 template <class T>
 static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     static bool attr_done = false;
@@ -351,6 +379,7 @@ static hipError_t launch_g_ks(const BConvArgs& a, int K, hipStream_t s) {
 
 hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
     switch (C) {
+        case 256: return launch_g_ks<G256>(a, K, s);
         case 128: return launch_g_ks<G128>(a, K, s);
         case 64: return launch_g_ks<G64>(a, K, s);
         case 32: return launch_g_ks<G32>(a, K, s);
@@ -369,9 +398,9 @@ const char* pair_g_kernel_name(int C, int K) {
 
 // ---- the fused-pair entry points the engine uses: which generation runs which channel count ----------------------
 bool pair_bf16_supported(int C, int K, int dil) {
-    return (C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
+    return (C == 256 || C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
 }
-static bool pair_uses_g(int C) { return C == 128 || C == 64; }  // measured per class with tools/kbench (profiles/r01_e_*)
+static bool pair_uses_g(int C) { return C == 256 || C == 128 || C == 64; }  // measured per class with tools/kbench (profiles/r01_e_*)
 BPackGeom pair_pack_geom(int C, int K) { return pair_uses_g(C) ? pair_g_pack_geom(C, K) : pair_lds_pack_geom(C, K); }
 hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
     return pair_uses_g(C) ? launch_pair_g_bf16(C, K, a, s) : launch_pair_lds_bf16(C, K, a, s);
