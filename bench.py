@@ -69,6 +69,22 @@ def cpu_baseline(reps: int = 3, T: int = 512):
     }
 
 
+def pmc_traffic(kernel: str, args, B: int, T: int):
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside a run (and never in the
+    same pass as a timed measurement): the number comes from the committed rocprofv3 --pmc passes of this same command
+    (profiles/traffic_<dtype>.json names them) and is reported only when kernel and launch problem match."""
+    path = os.path.join(REPO, "profiles", f"traffic_{args.dtype}.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if rec.get("kernel") != kernel or (B, T) != (64, 1024) or args.microbatch not in (0, 64):
+        return None
+    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"],
+            "source": rec["source"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,7 +187,7 @@ def main():
                 "peak": PEAK_TFLOPS[args.dtype],
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.dtype],
-                "traffic": None,
+                "traffic": pmc_traffic(prof["kernel"], args, B, T),
                 "kernel": prof["kernel"],
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / prof["launches"],
