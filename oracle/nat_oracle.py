@@ -1,0 +1,225 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU (numpy) restatement of the INFERENCE side of the reference's NAT networks
+(vietTTS/nat/model.py): ``DurationModel`` (:53-70) and ``AcousticModel.inference`` (:128-151), both built on
+``TokenEncoder`` (:9-50), taking Haiku-layout parameter / state dicts.
+
+**Parity unpinned.**  The reference's tests for these modules (tests/test_nat_duration.py,
+tests/test_nat_acoustic.py) assert output SHAPES only, ship no vector, and need jax + dm-haiku, which cannot be
+installed here; no NAT checkpoint ships with the reference either.  Unlike the HiFi-GAN
+oracle there is no second implementation inside the reference to pin against.  What is restated below is the
+published behaviour of the third-party modules the reference calls (dm-haiku / jax, unpinned in setup.py:6-19):
+
+* ``hk.Embed``        gather rows of ``embeddings[V, D]``
+* ``hk.Conv1D(C, k)`` default ``padding="SAME"``, stride 1: cross-correlation, ``w[k, Cin, Cout]``, pads ((k-1)//2, k//2)
+* ``hk.BatchNorm(True, True, 0.9)`` with ``is_training=False``:
+  ``(x - mean_ema) * scale * rsqrt(var_ema + 1e-5) + offset`` with the EMA ``average`` values of the state dict
+* ``hk.LSTM(H)``      ``gates = concat[x, h] @ w + b``; split order i, g, f, o; ``f = sigmoid(f + 1)``;
+  ``c' = f*c + sigmoid(i)*tanh(g)``; ``h' = sigmoid(o)*tanh(c')``
+* ``hk.ResetCore``    state <- initial state where ``should_reset``; at inference the mask (model.py:38) is True
+  only from position ``lengths - 1`` on, i.e. after flipping only at the first backward steps, where the state IS
+  the initial state (a no-op for ``lengths == L``; kept general here)
+* ``hk.deep_rnn_with_skip_connections([LSTM, LSTM])``: layer 2 sees ``concat[layer-1 output, network input]``;
+  the network output is ``concat`` of both layers' outputs
+* ``jax.nn.gelu`` default ``approximate=True`` (tanh form), ``jax.nn.softplus = logaddexp(x, 0)``
+* ``hk.dropout(key, rate, x)``: ``keep = bernoulli(key, 1 - rate)``; ``where(keep, x / (1 - rate), 0)``.  The keys
+  come from JAX's threefry PRNG through Haiku's per-scan-step splitting; that stream is NOT restated — callers pass
+  the keep masks explicitly (``prenet_masks``), so two implementations can be compared on identical masks.
+
+Only ``tests/`` may import this module.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import numpy as np
+
+BN_EPS = 1e-5  # hk.BatchNorm default eps
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def gelu_tanh(x):
+    """jax.nn.gelu(approximate=True)."""
+    c = x.dtype.type(np.sqrt(2.0 / np.pi))
+    return x.dtype.type(0.5) * x * (x.dtype.type(1.0) + np.tanh(c * (x + x.dtype.type(0.044715) * x * x * x)))
+
+
+def softplus(x):
+    """jax.nn.softplus = logaddexp(x, 0)."""
+    return np.logaddexp(x, x.dtype.type(0.0))
+
+
+def conv1d_same(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """hk.Conv1D(..., padding="SAME") on ``x [L, Cin]`` with ``w [k, Cin, Cout]`` (model.py:16-18, :91-92)."""
+    k = w.shape[0]
+    pl, pr = (k - 1) // 2, k // 2
+    L = x.shape[0]
+    xp = np.zeros((L + pl + pr, x.shape[1]), dtype=x.dtype)
+    xp[pl : pl + L] = x
+    y = np.broadcast_to(b.astype(x.dtype), (L, w.shape[2])).copy()
+    for j in range(k):
+        y += xp[j : j + L] @ w[j].astype(x.dtype)
+    return y
+
+
+def batchnorm_eval(x, scale, offset, mean, var):
+    """hk.BatchNorm(create_scale, create_offset, decay) with is_training=False (model.py:19-21, :29-36)."""
+    dt = x.dtype
+    inv = scale.reshape(-1).astype(dt) / np.sqrt(var.reshape(-1).astype(dt) + dt.type(BN_EPS))
+    return (x - mean.reshape(-1).astype(dt)) * inv + offset.reshape(-1).astype(dt)
+
+
+def lstm_step(x, h, c, w, b):
+    """hk.LSTM.__call__: gate order i, g, f, o; +1 on the forget gate."""
+    H = h.shape[-1]
+    gates = np.concatenate([x, h], axis=-1) @ w + b
+    i, g, f, o = gates[..., :H], gates[..., H : 2 * H], gates[..., 2 * H : 3 * H], gates[..., 3 * H :]
+    one = gates.dtype.type(1.0)
+    c2 = sigmoid(f + one) * c + sigmoid(i) * np.tanh(g)
+    h2 = sigmoid(o) * np.tanh(c2)
+    return h2, c2
+
+
+class Params:
+    """Access to a Haiku ``params`` / ``state`` pair by module-path suffix (the top-level prefix depends on how the
+    reference wrapped the module in hk.transform; only the tail is architectural)."""
+
+    def __init__(self, params: Dict[str, Dict[str, np.ndarray]], state: Dict[str, Dict[str, np.ndarray]], dtype):
+        self.p, self.s, self.dt = params, state, dtype
+
+    def get(self, suffix: str, name: str, state: bool = False) -> np.ndarray:
+        src = self.s if state else self.p
+        hits = [k for k in src if k == suffix or k.endswith("/" + suffix)]
+        if len(hits) != 1:
+            raise KeyError(f"{suffix!r}: {len(hits)} matches among {sorted(src)[:6]}...")
+        return np.asarray(src[hits[0]][name]).astype(self.dt)
+
+
+def token_encoder(P: Params, prefix: str, tokens: np.ndarray, length: int) -> np.ndarray:
+    """TokenEncoder.__call__ with is_training=False (model.py:26-50) for ONE sequence ``tokens [L]``.
+    Returns ``[L, 2*H]`` = concat(forward LSTM outputs, time-flipped backward LSTM outputs)."""
+    dt = P.dt
+    x = P.get(f"{prefix}/~/embed", "embeddings")[tokens]  # :27
+    for i, (cv, bn) in enumerate((("conv1_d", "batch_norm"), ("conv1_d_1", "batch_norm_1"), ("conv1_d_2", "batch_norm_2"))):
+        x = conv1d_same(x, P.get(f"{prefix}/~/{cv}", "w"), P.get(f"{prefix}/~/{cv}", "b"))
+        x = batchnorm_eval(
+            x,
+            P.get(f"{prefix}/~/{bn}", "scale"),
+            P.get(f"{prefix}/~/{bn}", "offset"),
+            P.get(f"{prefix}/~/{bn}/~/mean_ema", "average", state=True),
+            P.get(f"{prefix}/~/{bn}/~/var_ema", "average", state=True),
+        )
+        x = np.maximum(x, dt(0))  # jax.nn.relu (:28, :31, :34)
+    L = x.shape[0]
+    H = P.get(f"{prefix}/~/lstm/linear", "b").shape[0] // 4
+    mask = np.arange(L) >= (length - 1)  # :38
+    wf, bf_ = P.get(f"{prefix}/~/lstm/linear", "w"), P.get(f"{prefix}/~/lstm/linear", "b")
+    wb, bb = P.get(f"{prefix}/~/lstm_1/linear", "w"), P.get(f"{prefix}/~/lstm_1/linear", "b")
+    h = np.zeros(H, dt)
+    c = np.zeros(H, dt)
+    fwd = np.empty((L, H), dt)
+    for t in range(L):  # :39-40
+        h, c = lstm_step(x[t], h, c, wf, bf_)
+        fwd[t] = h
+    h = np.zeros(H, dt)
+    c = np.zeros(H, dt)
+    bwd = np.empty((L, H), dt)
+    xb, mb = x[::-1], mask[::-1]  # :41
+    for t in range(L):  # :42-45 — hk.ResetCore: reset BEFORE the step where the flag is set
+        if mb[t]:
+            h = np.zeros(H, dt)
+            c = np.zeros(H, dt)
+        h, c = lstm_step(xb[t], h, c, wb, bb)
+        bwd[t] = h
+    return np.concatenate([fwd, bwd[::-1]], axis=-1)  # :46
+
+
+def duration_model(params, state, tokens: np.ndarray, length: Optional[int] = None, dtype=np.float32) -> np.ndarray:
+    """DurationModel(is_training=False)(DurationInput(tokens[None], [len], None))[0] (model.py:53-70,
+    text2mel.py:22-34): seconds per token, ``[L]``."""
+    P = Params(params, state, dtype)
+    tokens = np.asarray(tokens, dtype=np.int64)
+    L = tokens.shape[0]
+    x = token_encoder(P, "duration_model/~/token_encoder", tokens, L if length is None else length)
+    x = x @ P.get("duration_model/~/linear", "w") + P.get("duration_model/~/linear", "b")  # :64-66
+    x = gelu_tanh(x)
+    x = x @ P.get("duration_model/~/linear_1", "w") + P.get("duration_model/~/linear_1", "b")
+    return softplus(x[:, 0])  # :69-70
+
+
+def gaussian_upsample(x: np.ndarray, durations: np.ndarray, n_frames: int) -> np.ndarray:
+    """AcousticModel.upsample (model.py:102-111) for one sequence: ``x [T, D]``, ``durations [T]`` in FRAMES."""
+    dt = x.dtype
+    ruler = np.arange(n_frames, dtype=dt)
+    end_pos = np.cumsum(durations.astype(dt))
+    mid_pos = end_pos - durations.astype(dt) / dt.type(2)
+    d2 = np.square(mid_pos[None, :] - ruler[:, None]) / dt.type(10.0)
+    z = -d2
+    z = z - z.max(axis=-1, keepdims=True)
+    w = np.exp(z)
+    w = w / w.sum(axis=-1, keepdims=True)
+    return w @ x
+
+
+def acoustic_inference(
+    params,
+    state,
+    tokens: np.ndarray,
+    durations_frames: np.ndarray,
+    n_frames: int,
+    prenet_masks: Optional[Callable[[int], Tuple[np.ndarray, np.ndarray]]] = None,
+    dtype=np.float32,
+) -> np.ndarray:
+    """AcousticModel(is_training=False).inference(tokens[None], durations[None], n_frames)[0] (model.py:128-151).
+
+    ``prenet_masks(t)`` returns the two boolean KEEP masks ``[256]`` of frame t's prenet dropout (rate 0.5, always on:
+    model.py:95-100); ``None`` = no dropout (the expectation-free deterministic variant used to compare
+    implementations).  Returns the mel ``[n_frames, mel_dim]``."""
+    P = Params(params, state, dtype)
+    dt = dtype
+    tokens = np.asarray(tokens, dtype=np.int64)
+    pre = "acoustic_model"
+    x = token_encoder(P, f"{pre}/~/token_encoder", tokens, tokens.shape[0])  # :131
+    cond = gaussian_upsample(x, np.asarray(durations_frames, dtype=dt), n_frames)  # :132
+    w1, b1 = P.get(f"{pre}/~/lstm/linear", "w"), P.get(f"{pre}/~/lstm/linear", "b")
+    w2, b2 = P.get(f"{pre}/~/lstm_1/linear", "w"), P.get(f"{pre}/~/lstm_1/linear", "b")
+    H = b1.shape[0] // 4
+    wp, bp = P.get(f"{pre}/~/linear", "w"), P.get(f"{pre}/~/linear", "b")  # projection (:85)
+    f1, f2 = P.get(f"{pre}/~/linear_1", "w"), P.get(f"{pre}/~/linear_2", "w")  # prenet_fc1/2, no bias (:88-89)
+    mel_dim = wp.shape[1]
+    prev = np.zeros(mel_dim, dt)
+    h1 = np.zeros(H, dt); c1 = np.zeros(H, dt); h2 = np.zeros(H, dt); c2 = np.zeros(H, dt)
+    out = np.empty((n_frames, mel_dim), dt)
+    two = dt(2.0)
+    for t in range(n_frames):  # loop_fn (:134-141)
+        p = np.maximum(prev @ f1, dt(0))
+        if prenet_masks is not None:
+            k1, k2 = prenet_masks(t)
+            p = np.where(k1, p * two, dt(0))
+        p = np.maximum(p @ f2, dt(0))
+        if prenet_masks is not None:
+            p = np.where(k2, p * two, dt(0))
+        xin = np.concatenate([cond[t], p])
+        h1, c1 = lstm_step(xin, h1, c1, w1, b1)
+        h2, c2 = lstm_step(np.concatenate([h1, xin]), h2, c2, w2, b2)
+        prev = np.concatenate([h1, h2]) @ wp + bp
+        out[t] = prev
+    # postnet (:113-121): 4 x (Conv1D(512, 5) + BatchNorm + tanh) + Conv1D(mel_dim, 5); residual added (:151)
+    y = out
+    for i in range(5):
+        cv = "conv1_d" if i == 0 else f"conv1_d_{i}"
+        y = conv1d_same(y, P.get(f"{pre}/~/{cv}", "w"), P.get(f"{pre}/~/{cv}", "b"))
+        if i < 4:
+            bn = "batch_norm" if i == 0 else f"batch_norm_{i}"
+            y = batchnorm_eval(
+                y,
+                P.get(f"{pre}/~/{bn}", "scale"),
+                P.get(f"{pre}/~/{bn}", "offset"),
+                P.get(f"{pre}/~/{bn}/~/mean_ema", "average", state=True),
+                P.get(f"{pre}/~/{bn}/~/var_ema", "average", state=True),
+            )
+            y = np.tanh(y)
+    return out + y

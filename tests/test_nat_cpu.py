@@ -1,0 +1,95 @@
+"""NAT duration model, CPU side: the oracle is self-consistent (fp32 vs fp64), the synthetic checkpoint carries exactly
+the arrays the C ABI asks for, and include/vtts_nat.h's symbols are all exported (no compute without a GPU)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import nat_oracle as no
+from viettts_amd import _lib
+from viettts_amd.nat.synth import synthetic_duration_checkpoint
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from viettts_amd.csrc.build import build
+
+    build()
+    return _lib.load()
+
+
+def test_nat_header_symbols_all_exported(lib):
+    header = (REPO / "include" / "vtts_nat.h").read_text()
+    declared = set(re.findall(r"\b(vtts_nat_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.NAT_EXPORTS), declared ^ set(_lib.NAT_EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_param_table_matches_synthetic_checkpoint(lib):
+    from viettts_amd.nat.duration import _lookup
+
+    h = C.c_void_p(0)
+    cfg = _lib.NatDurationCfg(256, 256)
+    _lib.check(lib, lib.vtts_nat_duration_create(C.byref(cfg), 0, C.byref(h)))
+    n = C.c_int(0)
+    _lib.check(lib, lib.vtts_nat_duration_num_params(h, C.byref(n)))
+    P, S = synthetic_duration_checkpoint()
+    seen = 0
+    for i in range(n.value):
+        mod, name = C.c_char_p(), C.c_char_p()
+        shape = (C.c_int64 * 3)()
+        nd = C.c_int(0)
+        _lib.check(lib, lib.vtts_nat_duration_param_info(h, i, C.byref(mod), C.byref(name), shape, C.byref(nd)))
+        a = _lookup(S if name.value == b"average" else P, mod.value.decode(), name.value.decode())
+        assert a.shape == tuple(shape[d] for d in range(nd.value)), (mod.value, name.value)
+        seen += 1
+    assert seen == sum(len([k for k in v if k in ("w", "b", "embeddings", "scale", "offset")]) for v in P.values()) + 6
+    # error paths: forward before pack, unknown array, wrong shape, bad sizes
+    assert lib.vtts_nat_duration_forward(h, C.c_void_p(256), C.c_void_p(256), 1, 4, C.c_void_p(256), C.c_void_p(256), 1 << 30, None) == -2
+    buf = (C.c_float * 4)()
+    shp = (C.c_int64 * 3)(1, 2, 3)
+    assert lib.vtts_nat_duration_set_param(h, b"nope", b"w", buf, shp, 3) == -1
+    assert lib.vtts_nat_duration_set_param(h, b"linear", b"w", buf, shp, 2) == -6
+    nb = C.c_size_t(0)
+    assert lib.vtts_nat_duration_workspace_bytes(h, 0, 4, C.byref(nb)) == -1
+    assert lib.vtts_nat_duration_pack(h, C.c_void_p(256), 1 << 30, None) == -3
+    lib.vtts_nat_duration_destroy(h)
+    bad = _lib.NatDurationCfg(256, 300)
+    assert lib.vtts_nat_duration_create(C.byref(bad), 0, C.byref(h)) == -1
+
+
+def test_oracle_fp32_vs_fp64_and_basic_properties():
+    P, S = synthetic_duration_checkpoint()
+    rng = np.random.default_rng(3)
+    for L in (1, 2, 37, 120):
+        tok = rng.integers(0, 100, size=L)
+        d32 = no.duration_model(P, S, tok, dtype=np.float32)
+        d64 = no.duration_model(P, S, tok, dtype=np.float64)
+        assert d32.shape == (L,) and np.all(d32 > 0)  # softplus
+        assert np.abs(d32 - d64).max() < 5e-6
+    # the backward LSTM sees the future: changing the last token changes the first duration; the forward one does not
+    # see it in its own half of the encoding
+    tok = rng.integers(0, 100, size=30)
+    tok2 = tok.copy()
+    tok2[-1] = (tok2[-1] + 1) % 100
+    assert no.duration_model(P, S, tok)[0] != no.duration_model(P, S, tok2)[0]
+
+
+def test_text2mel_frame_rules_on_oracle_durations():
+    """The integer quantities of text2mel.py:78-79, :99-101 from fp32 durations (oracle stands in for the network)."""
+    from viettts_amd.nat import text2mel as t2m
+    from viettts_amd.nat.config import FLAGS
+
+    P, S = synthetic_duration_checkpoint()
+    tokens = [FLAGS.sil_index, 10, 11, FLAGS.word_end_index, 12, FLAGS.word_end_index, FLAGS.sil_index]
+    d = no.duration_model(P, S, np.array(tokens))[None, :]
+    d = t2m.apply_duration_rules(tokens, d, 0.2)
+    assert d[0, 3] == 0 and d[0, 5] == 0 and d[0, 0] >= 0.2 and d[0, -1] >= 0.2
+    n = t2m.n_frames_from_durations(d)
+    assert n == int(np.float32(np.sum((d * np.float32(16000)) / np.float32(256), dtype=np.float32)))
+    assert t2m.trailing_silence_frames(d) == int(float(d[0, -1]) * 16000 / 256)

@@ -53,6 +53,25 @@ EXPORTS = (
 )
 
 
+# Every symbol include/vtts_nat.h declares.
+NAT_EXPORTS = (
+    "vtts_nat_duration_create",
+    "vtts_nat_duration_destroy",
+    "vtts_nat_duration_set_param",
+    "vtts_nat_duration_num_params",
+    "vtts_nat_duration_param_info",
+    "vtts_nat_duration_packed_bytes",
+    "vtts_nat_duration_pack",
+    "vtts_nat_duration_bind_packed",
+    "vtts_nat_duration_workspace_bytes",
+    "vtts_nat_duration_forward",
+)
+
+
+class NatDurationCfg(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("lstm_dim", C.c_int32)]
+
+
 class VttsError(RuntimeError):
     """A C-ABI call returned a negative vtts_status."""
 
@@ -148,6 +167,16 @@ def load(path=None) -> C.CDLL:
         "vtts_hifigan_get_option": (C.c_int, [vp, cp, C.POINTER(i64)]),
         "vtts_hifigan_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
         "vtts_hifigan_profile_kernel": (cp, [vp]),
+        "vtts_nat_duration_create": (C.c_int, [C.POINTER(NatDurationCfg), C.c_int, C.POINTER(vp)]),
+        "vtts_nat_duration_destroy": (None, [vp]),
+        "vtts_nat_duration_set_param": (C.c_int, [vp, cp, cp, vp, C.POINTER(i64), C.c_int]),
+        "vtts_nat_duration_num_params": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "vtts_nat_duration_param_info": (C.c_int, [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), C.POINTER(C.c_int)]),
+        "vtts_nat_duration_packed_bytes": (C.c_int, [vp, C.POINTER(sz)]),
+        "vtts_nat_duration_pack": (C.c_int, [vp, vp, sz, vp]),
+        "vtts_nat_duration_bind_packed": (C.c_int, [vp, vp, sz]),
+        "vtts_nat_duration_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(sz)]),
+        "vtts_nat_duration_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -35,6 +35,16 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+
+// shared with nat.hip: record the calling thread's last error, return the status code
+int vtts::set_error(int code, const char* msg) {
+    g_last_error = msg;
+    return code;
+}
+
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \

@@ -7,6 +7,9 @@
 
 namespace vtts {
 
+// engine.hip: record the calling thread's last error message (vtts_last_error()) and return `code`
+int set_error(int code, const char* msg);
+
 // How a convolution's result is combined with what is already in memory.  This is where
 // ResBlock1's residual (model.py:50 `x = xt + x`) and the MRF mean (model.py:115-121
 // `xs = rb0; xs += rb1; xs += rb2; x = xs / 3`) are fused into the producing kernel.

@@ -1,12 +1,15 @@
 """Constants of the NAT front end that the call surface needs (reference: vietTTS/nat/config.py:8-59).
 
-Only what ``text2tokens`` / the frame-count arithmetic / the CLI read is mirrored here; model
-dimensions and training knobs belong to rows of SURVEY.md §8f that are not built yet.
+Only what ``text2tokens`` / the frame-count arithmetic / the duration model / the CLI read is mirrored here;
+training knobs and the acoustic model's dimensions belong to rows of SURVEY.md §8f that are not built yet.
 """
 from pathlib import Path
 
 
 class FLAGS:
+    # model dimensions (config.py:11-17)
+    duration_lstm_dim = 256
+    vocab_size = 256
     # Montreal-Forced-Aligner specials: [sil] [sp] [spn] [word end]   (config.py:24-27)
     special_phonemes = ["sil", "sp", "spn", " "]
     sil_index = 0

@@ -1,0 +1,37 @@
+"""Deterministic synthetic checkpoints of the NAT duration model (no pretrained NAT checkpoint exists offline: the
+reference fetches them with wget, scripts/quick_start.sh).  Haiku-layout ``params`` / ``state`` dicts with the module
+paths text2mel.py:23-24 produces (``duration_model/~/...``), drawn from a CPU numpy Generator so that a seed gives
+the same bits on every box.  Scales keep the activations O(1) through the stack (fan-in scaled weights, BatchNorm
+statistics near (0, 1)) and the predicted durations around 0.1 s per token."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .config import FLAGS
+
+HaikuDict = Dict[str, Dict[str, np.ndarray]]
+
+
+def synthetic_duration_checkpoint(seed: int = 777, vocab_size: int = FLAGS.vocab_size, dim: int = FLAGS.duration_lstm_dim) -> Tuple[HaikuDict, HaikuDict]:
+    g = np.random.default_rng(seed)
+    f32 = np.float32
+
+    def n(*shape, scale=1.0):
+        return (g.standard_normal(shape) * scale).astype(f32)
+
+    pre = "duration_model/~/token_encoder/~/"
+    P: HaikuDict = {pre + "embed": {"embeddings": n(vocab_size, dim)}}
+    S: HaikuDict = {}
+    for i in range(3):
+        sfx = f"_{i}" if i else ""
+        P[pre + "conv1_d" + sfx] = {"w": n(3, dim, dim, scale=(2.0 / (3 * dim)) ** 0.5), "b": n(dim, scale=0.05)}
+        P[pre + "batch_norm" + sfx] = {"scale": (1.0 + n(1, 1, dim, scale=0.1)).astype(f32), "offset": n(1, 1, dim, scale=0.1)}
+        S[pre + "batch_norm" + sfx + "/~/mean_ema"] = {"average": n(1, 1, dim, scale=0.2), "hidden": n(1, 1, dim), "counter": np.array(1000, np.int32)}
+        S[pre + "batch_norm" + sfx + "/~/var_ema"] = {"average": (1.0 + np.abs(n(1, 1, dim, scale=0.3))).astype(f32), "hidden": n(1, 1, dim), "counter": np.array(1000, np.int32)}
+    for l in ("lstm", "lstm_1"):
+        P[pre + l + "/linear"] = {"w": n(2 * dim, 4 * dim, scale=(1.0 / (2 * dim)) ** 0.5), "b": n(4 * dim, scale=0.05)}
+    P["duration_model/~/linear"] = {"w": n(2 * dim, dim, scale=(1.0 / (2 * dim)) ** 0.5 * 3.0), "b": n(dim, scale=0.05)}
+    P["duration_model/~/linear_1"] = {"w": n(dim, 1, scale=(1.0 / dim) ** 0.5 * 2.0), "b": np.array([-2.0], f32)}
+    return P, S

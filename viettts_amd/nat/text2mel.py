@@ -7,11 +7,13 @@ What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
     same dtype and operation order (fp32 multiply by 16000, fp32 divide by 256, fp32 sum, truncate);
   * ``text2mel(text, lexicon_fn, silence_duration)`` with the reference's signature.
 
-What is NOT built yet: the NAT duration and acoustic networks themselves (vietTTS/nat/model.py —
-BiLSTM encoder, autoregressive 2xLSTM decoder with always-on prenet dropout driven by JAX's threefry
-PRNG).  They are "next" rows, upstream of the hot path; ``text2mel`` therefore raises
-``NotImplementedError`` unless a mel provider has been registered with :func:`set_mel_provider`
-(tests and the CLI's ``--mel-file`` use that hook).
+  * ``predict_duration(tokens)`` (:22-34) on the MI355X: the NAT duration model (vietTTS/nat/model.py:9-70) runs in
+    the HIP library behind include/vtts_nat.h (viettts_amd/nat/duration.py); there is no CPU path.
+
+What is NOT built yet: the NAT acoustic network (vietTTS/nat/model.py:73-171 — autoregressive 2xLSTM decoder with
+always-on prenet dropout driven by JAX's threefry PRNG).  ``text2mel`` therefore raises ``NotImplementedError``
+unless a mel provider has been registered with :func:`set_mel_provider` (tests and the CLI's ``--mel-file`` use
+that hook).
 """
 from __future__ import annotations
 
@@ -85,6 +87,42 @@ def trailing_silence_frames(durations: np.ndarray) -> int:
     (text2mel.py:99-101): the fp32 duration is widened to double by ``.item()`` first."""
     end_silence = float(np.asarray(durations, dtype=np.float32)[0, -1])
     return int(end_silence * FLAGS.sample_rate / (FLAGS.n_fft // 4))
+
+
+_DURATION_MODEL = None
+
+
+def load_duration_checkpoint(path=None):
+    """``dic["params"], dic["aux"]`` of ``duration_latest_ckpt.pickle`` (text2mel.py:27-28, written by
+    vietTTS/nat/utils.py:18-24).  Checkpoints whose dicts were pickled as plain numpy dicts load as they are; ones
+    holding Haiku FlatMapping / jax arrays need those libraries to unpickle, as in the reference."""
+    import pickle
+
+    path = FLAGS.ckpt_dir / "duration_latest_ckpt.pickle" if path is None else path
+    with open(path, "rb") as f:
+        dic = pickle.load(f)
+    to_np = lambda d: {k: {n: np.asarray(a) for n, a in dict(v).items()} for k, v in dict(d).items()}
+    return to_np(dic["params"]), to_np(dic["aux"])
+
+
+def set_duration_model(model) -> None:
+    """Install a loaded :class:`viettts_amd.nat.duration.DurationModel` for :func:`predict_duration` (tests install
+    one with synthetic weights; by default the checkpoint under FLAGS.ckpt_dir is loaded on first use)."""
+    global _DURATION_MODEL
+    _DURATION_MODEL = model
+
+
+def predict_duration(tokens: Sequence[int]) -> np.ndarray:
+    """Reference signature and result (text2mel.py:22-34): float32 ``[1, L]`` seconds per token, computed on the GPU."""
+    global _DURATION_MODEL
+    if _DURATION_MODEL is None:
+        from .duration import DurationModel
+
+        params, state = load_duration_checkpoint()  # FileNotFoundError if absent, as in the reference
+        m = DurationModel()
+        m.load_params(params, state)
+        _DURATION_MODEL = m
+    return _DURATION_MODEL([list(tokens)])[0][None, :]
 
 
 _MEL_PROVIDER: Optional[Callable] = None
