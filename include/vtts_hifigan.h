@@ -154,7 +154,8 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  * Engine options (tests / benchmarks):
  *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
  *   "microbatch" utterances processed per pass through the network (0 = auto)
- *   "fuse"      bf16: 1 = fused ResBlock-pair kernel (default), 0 = one kernel per convolution
+ *   "fuse"      bf16: 2 = fused ResBlock pairs + the whole-ResBlock kernel of the C = 32 stage where it is the faster
+ *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
  *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow

@@ -136,7 +136,7 @@ def test_conv_pre_and_post_bf16(gen, v1_params, dev):
     assert np.abs(y - ref).max() < 1e-5
 
 
-@pytest.mark.parametrize("fuse", [1, 0], ids=["fused-pairs", "per-conv"])
+@pytest.mark.parametrize("fuse", [3, 2, 1, 0], ids=["fused-resblocks-all", "fused-resblocks", "fused-pairs", "per-conv"])
 def test_generator_bf16_vs_reference_golden(golden_dir, gen, dev, capsys, fuse):
     """End-to-end error of the bf16 path against the reference's fp64 output (reported, loosely bounded)."""
     meta = json.load(open(golden_dir / "golden_meta.json"))["cases"]
@@ -153,7 +153,7 @@ def test_generator_bf16_vs_reference_golden(golden_dir, gen, dev, capsys, fuse):
         snr = 10 * np.log10((g["pre64"] ** 2).mean() / ((pre.cpu().numpy() - g["pre64"]) ** 2).mean())
         worst[case] = (e_y, e_p, float(snr))
         assert e_y < 0.05 and e_p < 0.05 and snr > 35.0, worst
-    gen.set_option("fuse", 1)
+    gen.set_option("fuse", 2)
     with capsys.disabled():
         print("\n[bf16 end-to-end vs fp64 reference] (max|dy|, max|dpre|, SNR dB):", worst)
 
@@ -171,6 +171,25 @@ def test_bf16_taps_vs_oracle(gen, v1_params, dev):
         torch.cuda.synchronize()
         got = got.cpu().numpy().reshape(want.shape)
         assert _rel(got, want) < 0.05, (name, _rel(got, want))
+
+
+@pytest.mark.parametrize("T", [1, 3, 37, 300], ids=lambda t: f"T{t}")
+def test_fused_resblock32_equals_pair_path(gen, dev, T):
+    """The whole-ResBlock kernel of the C = 32 stage (fuse = 2) against the pair-by-pair path (fuse = 1): same operands,
+    same bf16 rounding points, only fp32 summation order (bias first vs last) differs -> a few output ulps.  T = 1, 3:
+    utterances shorter than every halo; 37, 300: several ragged 392..488-column windows, both utterance edges."""
+    mel = torch.from_numpy(synthetic_mel(2, T, 31 + T)).to(dev)
+    out = {}
+    for fuse in (3, 2, 1):  # 3: the ResBlock kernel for k = 3, 7, 11; 2: for k = 3, 7 (the default); 1: pairs only
+        gen.set_option("fuse", fuse)
+        wav, tap = gen.forward_tap(mel, "mrf_3")
+        torch.cuda.synchronize()
+        out[fuse] = (wav.cpu().numpy().copy(), tap.cpu().numpy().copy())
+    gen.set_option("fuse", 2)
+    ref = out[1][1]
+    for fuse in (3, 2):
+        assert np.abs(out[fuse][1] - ref).max() <= 2.0 ** -6 * np.abs(ref).max(), (fuse, np.abs(out[fuse][1] - ref).max(), np.abs(ref).max())
+        assert np.abs(out[fuse][0] - out[1][0]).max() < 0.02
 
 
 def test_bf16_batch_and_microbatch_invariance(gen, dev):

@@ -74,6 +74,9 @@ struct Layer {
     // fused pair (this layer = convs1_z, next layer = convs2_z): [c1 slabs][c2 slabs] + [b1][b2]
     bool has_pair = false;
     size_t off_pw = 0, pw_bytes = 0, off_pb = 0;
+    // whole ResBlock (this layer = convs1_0 of a C = 32 ResBlock): six convolutions' slabs + six biases
+    bool has_rb = false;
+    size_t off_rw = 0, rw_bytes = 0, off_rb = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -96,7 +99,7 @@ struct vtts_hifigan {
     int64_t opt_microbatch = 0;      // 0 auto
     int64_t opt_profile = 0;
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
-    int64_t opt_fuse = 1;            // bf16: fused ResBlock pair kernel (1) or one kernel per convolution (0)
+    int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
     int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -183,6 +186,22 @@ int build_layers_bf16(vtts_hifigan* h) {
             c1.off_pb = off;
             off = align_up(off + (size_t)2 * c1.cin * sizeof(float), 256);
         }
+    }
+    for (size_t r = 0; r < h->idx_res.size(); ++r) {
+        Layer& c0 = h->layers[h->idx_res[r]];
+        const int dils[3] = {h->layers[h->idx_res[r] + 0].dil, h->layers[h->idx_res[r] + 2].dil, h->layers[h->idx_res[r] + 4].dil};
+        bool ok = resblock32_bf16_supported(c0.cin, c0.k, dils);
+        for (int q = 0; q < 6 && ok; ++q) {
+            const Layer& l = h->layers[h->idx_res[r] + q];
+            ok = l.cin == c0.cin && l.cout == c0.cin && l.k == c0.k && ((q & 1) ? l.dil == 1 : true);
+        }
+        if (!ok) continue;
+        c0.has_rb = true;
+        c0.rw_bytes = 6 * bf16_packed_bytes(pair_g_pack_geom(c0.cin, c0.k));
+        c0.off_rw = off;
+        off = align_up(off + c0.rw_bytes, 256);
+        c0.off_rb = off;
+        off = align_up(off + (size_t)6 * c0.cin * sizeof(float), 256);
     }
     h->blob_bytes = off;
     for (auto& l : h->layers)
@@ -438,6 +457,30 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     return VTTS_OK;
 }
 
+int run_resblock32_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, int L, float slope_out, void* y, int acc_add, float div,
+                        hipStream_t s) {
+    BConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.wp = h->blob + rb[0].off_rw;
+    a.bias = reinterpret_cast<const float*>(h->blob + rb[0].off_rb);
+    a.y = y;
+    a.B = B;
+    a.L = L;
+    a.x_pitch = rb[0].cin;
+    a.cin_real = rb[0].cin;
+    a.dils[0] = rb[0].dil;
+    a.dils[1] = rb[2].dil;
+    a.dils[2] = rb[4].dil;
+    a.slope_in = 0.1f;
+    a.slope_out = slope_out;
+    a.acc_add = acc_add;
+    a.div = div;
+    hipError_t e = launch_resblock32_bf16(rb[0].k, a, s);
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused ResBlock launch for %s failed: %s", rb[0].key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 struct Taps;
 int tap_copy_bf16(const void* src, float* dst, size_t n, hipStream_t s) {
     hipError_t e = launch_bf16_to_f32(src, dst, n, s);
@@ -566,6 +609,15 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 const int base = h->idx_res[i * nk + j];
                 const char* cur = bufX;
                 const bool last_rb = (j == nk - 1);
+                // measured (profiles/r01_f_*): the whole-ResBlock kernel wins for k = 3, 7 (1.25 / 2.21 ms vs 1.83 / 2.56 ms as
+                // three pairs) and loses slightly for k = 11 (3.44 vs 3.28 ms: 23 % of its window is halo); fuse = 3 forces it
+                if (h->opt_fuse >= 2 && h->layers[base].has_rb && (h->opt_fuse >= 3 || h->layers[base].k < 11)) {
+                    // the whole ResBlock in one kernel: X -> S (store / accumulate / accumulate-and-divide)
+                    rc = run_resblock32_bf16(h, &h->layers[base], cur, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
+                                             last_rb ? (float)nk : 1.0f, s);
+                    if (rc) return rc;
+                    continue;
+                }
                 if (h->opt_fuse && h->layers[base].has_pair && h->layers[base + 2].has_pair && h->layers[base + 4].has_pair) {
                     // fused pairs cannot run in place (a neighbour tile's halo would see updated rows):
                     // X -> T -> C -> S, with X kept for the other ResBlocks of the stage
@@ -871,6 +923,18 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
             memcpy(pb, c1.b.data(), c1.cin * sizeof(float));
             memcpy(pb + c1.cin, c2.b.data(), c1.cin * sizeof(float));
         }
+        for (size_t i = 0; i + 5 < h->layers.size(); ++i) {
+            const Layer& c0 = h->layers[i];
+            if (!c0.has_rb) continue;
+            const BPackGeom pg = pair_g_pack_geom(c0.cin, c0.k);
+            const size_t one = bf16_packed_bytes(pg);
+            float* rb = reinterpret_cast<float*>(host.data() + c0.off_rb);
+            for (int q = 0; q < 6; ++q) {
+                const Layer& l = h->layers[i + q];
+                bf16_pack(l.w.data(), l.cin, pg, reinterpret_cast<unsigned short*>(host.data() + c0.off_rw + q * one));
+                memcpy(rb + (size_t)q * c0.cin, l.b.data(), c0.cin * sizeof(float));
+            }
+        }
     }
     for (auto& l : h->layers) {
         if (h->dtype == VTTS_BF16) break;
@@ -1028,7 +1092,8 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
         if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
         h->opt_microbatch = value;
     } else if (!strcmp(name, "fuse")) {
-        h->opt_fuse = value ? 1 : 0;
+        if (value < 0 || value > 3) return fail(VTTS_ERR_INVALID, "fuse must be 0 (per convolution), 1 (pairs), 2 (pairs + C=32 ResBlocks where faster) or 3 (... wherever supported)");
+        h->opt_fuse = value;
     } else if (!strcmp(name, "streams")) {
         if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
         h->opt_streams = value;

@@ -80,6 +80,7 @@ struct BConvArgs {
     int x_pitch;          // elements per input row in global memory
     int cin_real;         // valid input channels (conv_pre: 80)
     int dil, pad;
+    int dils[3];          // whole-ResBlock kernel: the three pairs' rates
     float slope_in;       // LeakyReLU applied to the input while staging (1 = producer already did it)
     float slope_out;      // LeakyReLU applied to the stored output (the consumer's activation), 1 = none
     int acc_add;          // y = y + v   (MRF accumulate)
@@ -109,6 +110,10 @@ const char* pair_g_kernel_name(int C, int K);
 hipError_t launch_pair_lds_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 BPackGeom pair_lds_pack_geom(int C, int K);
 const char* pair_lds_kernel_name(int C, int K);
+// whole ResBlock1 of the C = 32 stage in one kernel (kernels_bf16_rb32.hip)
+bool resblock32_bf16_supported(int C, int K, const int* dils);
+hipError_t launch_resblock32_bf16(int K, const BConvArgs& a, hipStream_t s);
+const char* resblock32_kernel_name(int K);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
