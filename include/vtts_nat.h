@@ -1,6 +1,6 @@
 /*
- * vtts_nat.h — C ABI of the MI355X-native NAT duration model of NTT123/vietTTS (the caller-side row next to
- * the mel->waveform hot path: it decides how many mel frames mel2wave() will see).
+ * vtts_nat.h — C ABI of the MI355X-native NAT duration and acoustic models of NTT123/vietTTS (the caller-side rows
+ * next to the mel->waveform hot path: they decide how many mel frames mel2wave() will see, and produce them).
  *
  * Entry points a maintainer of the reference would bind (ctypes stub in INTEGRATION.md) to replace the body of
  *     vietTTS/nat/text2mel.py:22-34   predict_duration(tokens)
@@ -63,6 +63,48 @@ int vtts_nat_duration_workspace_bytes(const vtts_nat_duration* h, int B, int Lma
  */
 int vtts_nat_duration_forward(vtts_nat_duration* h, const int32_t* tokens_dev, const int32_t* lengths_dev, int B, int Lmax,
                               float* durations_dev, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Acoustic model: replaces predict_mel()'s network apply, vietTTS/nat/text2mel.py:61-82 ==
+ * AcousticModel(is_training=False).inference(tokens, durations, n_frames), vietTTS/nat/model.py:128-151.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct vtts_nat_acoustic_cfg { /* vietTTS/nat/config.py:11-17, :42; model.py:88-89 */
+    int32_t vocab_size;   /* 256 */
+    int32_t encoder_dim;  /* acoustic_encoder_dim 256 */
+    int32_t decoder_dim;  /* acoustic_decoder_dim 512 */
+    int32_t prenet_dim;   /* 256 (hk.Linear(256) x 2) */
+    int32_t mel_dim;      /* 80  */
+    int32_t postnet_dim;  /* 512 */
+} vtts_nat_acoustic_cfg;
+
+typedef struct vtts_nat_acoustic vtts_nat_acoustic; /* opaque */
+
+int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int device, vtts_nat_acoustic** out);
+void vtts_nat_acoustic_destroy(vtts_nat_acoustic* h);
+/* Arrays by Haiku module tail under "acoustic_model/~/": "token_encoder/~/..." as above; "lstm/linear", "lstm_1/linear"
+ * (decoder layers), "linear" (mel projection), "linear_1" / "linear_2" (prenet, "w" only), "conv1_d" .. "conv1_d_4" and
+ * "batch_norm" .. "batch_norm_3" (+ "/~/mean_ema", "/~/var_ema" state) of the postnet. */
+int vtts_nat_acoustic_set_param(vtts_nat_acoustic* h, const char* module, const char* name, const float* host,
+                                const int64_t* shape, int ndim);
+int vtts_nat_acoustic_num_params(const vtts_nat_acoustic* h, int* n);
+int vtts_nat_acoustic_param_info(const vtts_nat_acoustic* h, int i, const char** module, const char** name,
+                                 int64_t shape[3], int* ndim);
+int vtts_nat_acoustic_packed_bytes(const vtts_nat_acoustic* h, size_t* bytes);
+int vtts_nat_acoustic_pack(vtts_nat_acoustic* h, void* dev_blob, size_t blob_bytes, void* stream);
+int vtts_nat_acoustic_bind_packed(vtts_nat_acoustic* h, void* dev_blob, size_t blob_bytes);
+int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lmax, int Fmax, size_t* bytes);
+/*
+ *   tokens_dev    [B, Lmax] int32, lengths_dev [B] int32                       as for the duration model
+ *   durations_dev [B, Lmax] fp32, in FRAMES (text2mel.py:78: seconds * sample_rate / hop)
+ *   nframes_dev   [B] int32: frames to generate per sentence (text2mel.py:79), <= Fmax
+ *   keep_dev      [B, Fmax, 2, prenet_dim] bytes: the prenet's two dropout KEEP masks per frame (1 = keep and scale by 2;
+ *                 model.py:95-100 — dropout is on at inference), or NULL for no dropout.  The reference draws them from
+ *                 JAX's threefry PRNG through Haiku's per-scan-step key splitting; that stream is the caller's business.
+ *   mel_dev       [B, Fmax, mel_dim] fp32 log-mel (decoder output + postnet residual); rows past nframes are zero
+ */
+int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
+                              const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
+                              const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -81,3 +81,89 @@ def test_predict_duration_surface(model):
         assert np.abs(d[0] - no.duration_model(P, S, np.array(tokens), dtype=np.float64)).max() < 2e-6
     finally:
         t2m.set_duration_model(None)
+
+
+# ------------------------------------------------ acoustic model ------------------------------------------------
+@pytest.fixture(scope="module")
+def acoustic():
+    from viettts_amd.nat.acoustic import AcousticModel
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint
+
+    m = AcousticModel(device="cuda:0")
+    P, S = synthetic_acoustic_checkpoint()
+    m.load_params(P, S)
+    yield m, P, S
+    m.close()
+
+
+def _case(seed, L):
+    rng = np.random.default_rng(seed)
+    tok = list(rng.integers(0, 100, size=L))
+    dur = np.abs(rng.normal(3.0, 1.5, size=L)).astype(np.float32)  # frames per token
+    dur[rng.integers(0, L)] = 0.0  # a word-end token (text2mel.py:95-97)
+    nf = max(1, int(np.sum(dur, dtype=np.float32)))
+    return tok, dur, nf
+
+
+def test_acoustic_matches_oracle_no_dropout(acoustic):
+    m, P, S = acoustic
+    cases = [_case(21, 1), _case(22, 7), _case(23, 30)]
+    got = m([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    for (tok, dur, nf), g in zip(cases, got):
+        ref = no.acoustic_inference(P, S, np.array(tok), dur, nf, dtype=np.float64)
+        assert g.shape == ref.shape == (nf, 80)
+        # an autoregressive fp32 loop over up to ~100 frames: errors of single steps (~1e-6) compound mildly
+        assert np.abs(g - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), np.abs(g - ref).max()
+
+
+def test_acoustic_matches_oracle_with_explicit_dropout_masks(acoustic):
+    from viettts_amd.nat.acoustic import bernoulli_keep_masks
+
+    m, P, S = acoustic
+    tok, dur, nf = _case(24, 20)
+    keep = bernoulli_keep_masks(nf, seed=5)
+    g = m([tok], [dur], [nf], keep_masks=[keep])[0]
+    ref = no.acoustic_inference(P, S, np.array(tok), dur, nf, prenet_masks=lambda t: (keep[t, 0], keep[t, 1]), dtype=np.float64)
+    assert np.abs(g - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+    # and the masks matter: without them the mel differs
+    g0 = m([tok], [dur], [nf])[0]
+    assert np.abs(g - g0).max() > 1e-3
+
+
+def test_acoustic_rows_independent(acoustic):
+    m, P, S = acoustic
+    cases = [_case(31, 9), _case(32, 25)]
+    both = m([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    for c, g in zip(cases, both):
+        assert np.array_equal(m([c[0]], [c[1]], [c[2]])[0], g)
+
+
+def test_text2mel_to_waveform_pipeline(model, acoustic, tmp_path):
+    """BASELINE configs[3] in miniature on one GPU: text -> tokens -> durations (GPU) -> frame rules -> mel (GPU) ->
+    HiFi-GAN (GPU), all through the reference's call surface, synthetic checkpoints."""
+    from viettts_amd.hifigan.config import V1
+    from viettts_amd.hifigan.generator import Generator
+    from viettts_amd.hifigan.synth import synthetic_params
+
+    dm, _, _ = model
+    am, _, _ = acoustic
+    lex = tmp_path / "lexicon.txt"
+    lex.write_text("xin\tx i n\nchào\tc h à o\n", encoding="utf-8")
+    t2m.set_duration_model(dm)
+    t2m.set_acoustic_model(am)
+    try:
+        text = "xin chào sp việt nam"
+        tokens = t2m.text2tokens(text, lex)
+        mel = t2m.text2mel(text, lex, silence_duration=0.2)
+        d = t2m.apply_duration_rules(tokens, t2m.predict_duration(tokens), 0.2)
+        want_frames = t2m.n_frames_from_durations(d) - t2m.trailing_silence_frames(d)
+        assert mel.shape == (1, want_frames, 80) and mel.dtype == np.float32 and np.isfinite(mel).all()
+        assert np.array_equal(mel, t2m.text2mel(text, lex, silence_duration=0.2))  # same dropout seed -> same mel
+        gen = Generator(V1, device="cuda:0", dtype="bf16")
+        gen.load_params(synthetic_params(V1, 4321, "scaled"))
+        wav = gen(torch.from_numpy(mel).to("cuda:0")).cpu().numpy()
+        gen.close()
+        assert wav.shape == (1, 256 * want_frames) and np.isfinite(wav).all() and np.abs(wav).max() < 1.0
+    finally:
+        t2m.set_duration_model(None)
+        t2m.set_acoustic_model(None)

@@ -93,3 +93,45 @@ def test_text2mel_frame_rules_on_oracle_durations():
     n = t2m.n_frames_from_durations(d)
     assert n == int(np.float32(np.sum((d * np.float32(16000)) / np.float32(256), dtype=np.float32)))
     assert t2m.trailing_silence_frames(d) == int(float(d[0, -1]) * 16000 / 256)
+
+
+def test_acoustic_param_table_matches_synthetic_checkpoint(lib):
+    from viettts_amd.nat.duration import _lookup
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint
+
+    h = C.c_void_p(0)
+    cfg = _lib.NatAcousticCfg(256, 256, 512, 256, 80, 512)
+    _lib.check(lib, lib.vtts_nat_acoustic_create(C.byref(cfg), 0, C.byref(h)))
+    n = C.c_int(0)
+    _lib.check(lib, lib.vtts_nat_acoustic_num_params(h, C.byref(n)))
+    P, S = synthetic_acoustic_checkpoint()
+    for i in range(n.value):
+        mod, name = C.c_char_p(), C.c_char_p()
+        shape = (C.c_int64 * 3)()
+        nd = C.c_int(0)
+        _lib.check(lib, lib.vtts_nat_acoustic_param_info(h, i, C.byref(mod), C.byref(name), shape, C.byref(nd)))
+        a = _lookup(S if name.value == b"average" else P, "acoustic_model/~/" + mod.value.decode(), name.value.decode())
+        assert a.shape == tuple(shape[d] for d in range(nd.value)), (mod.value, name.value)
+    n_ckpt = sum(len([k for k in v if k != "hidden" and k != "counter"]) for v in list(P.values()) + list(S.values()))
+    assert n.value == n_ckpt
+    nb = C.c_size_t(0)
+    assert lib.vtts_nat_acoustic_workspace_bytes(h, 1, 10, 0, C.byref(nb)) == -1
+    lib.vtts_nat_acoustic_destroy(h)
+    bad = _lib.NatAcousticCfg(256, 256, 256, 256, 80, 512)  # decoder_dim != 512
+    assert lib.vtts_nat_acoustic_create(C.byref(bad), 0, C.byref(h)) == -1
+
+
+def test_acoustic_oracle_properties():
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint
+
+    P, S = synthetic_acoustic_checkpoint()
+    tok = np.random.default_rng(0).integers(0, 100, size=6)
+    dur = np.array([2.0, 3.5, 0.0, 4.0, 1.5, 3.0], np.float32)
+    nf = int(dur.sum())
+    m32 = no.acoustic_inference(P, S, tok, dur, nf, dtype=np.float32)
+    m64 = no.acoustic_inference(P, S, tok, dur, nf, dtype=np.float64)
+    assert m32.shape == (nf, 80) and np.abs(m32 - m64).max() < 1e-4
+    # Gaussian upsampling rows are convex combinations of encoder rows (weights sum to 1)
+    x = np.eye(6, dtype=np.float64)
+    w = no.gaussian_upsample(x, dur.astype(np.float64), nf)
+    assert np.allclose(w.sum(axis=1), 1.0) and w.min() >= 0

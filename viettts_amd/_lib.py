@@ -65,11 +65,25 @@ NAT_EXPORTS = (
     "vtts_nat_duration_bind_packed",
     "vtts_nat_duration_workspace_bytes",
     "vtts_nat_duration_forward",
+    "vtts_nat_acoustic_create",
+    "vtts_nat_acoustic_destroy",
+    "vtts_nat_acoustic_set_param",
+    "vtts_nat_acoustic_num_params",
+    "vtts_nat_acoustic_param_info",
+    "vtts_nat_acoustic_packed_bytes",
+    "vtts_nat_acoustic_pack",
+    "vtts_nat_acoustic_bind_packed",
+    "vtts_nat_acoustic_workspace_bytes",
+    "vtts_nat_acoustic_forward",
 )
 
 
 class NatDurationCfg(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("lstm_dim", C.c_int32)]
+
+
+class NatAcousticCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "encoder_dim", "decoder_dim", "prenet_dim", "mel_dim", "postnet_dim")]
 
 
 class VttsError(RuntimeError):
@@ -177,6 +191,16 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_duration_bind_packed": (C.c_int, [vp, vp, sz]),
         "vtts_nat_duration_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(sz)]),
         "vtts_nat_duration_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, sz, vp]),
+        "vtts_nat_acoustic_create": (C.c_int, [C.POINTER(NatAcousticCfg), C.c_int, C.POINTER(vp)]),
+        "vtts_nat_acoustic_destroy": (None, [vp]),
+        "vtts_nat_acoustic_set_param": (C.c_int, [vp, cp, cp, vp, C.POINTER(i64), C.c_int]),
+        "vtts_nat_acoustic_num_params": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "vtts_nat_acoustic_param_info": (C.c_int, [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.POINTER(i64), C.POINTER(C.c_int)]),
+        "vtts_nat_acoustic_packed_bytes": (C.c_int, [vp, C.POINTER(sz)]),
+        "vtts_nat_acoustic_pack": (C.c_int, [vp, vp, sz, vp]),
+        "vtts_nat_acoustic_bind_packed": (C.c_int, [vp, vp, sz]),
+        "vtts_nat_acoustic_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(sz)]),
+        "vtts_nat_acoustic_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

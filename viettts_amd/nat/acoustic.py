@@ -1,0 +1,123 @@
+"""Host-side owner of the NAT acoustic model on one GPU.
+
+Mirrors the network apply inside ``predict_mel(tokens, durations)`` of the reference (vietTTS/nat/text2mel.py:61-82):
+``AcousticModel(is_training=False).inference(tokens, durations, n_frames)`` (vietTTS/nat/model.py:128-151) with the
+checkpoint's ``params`` / ``aux`` dicts.  All arithmetic happens in the HIP library (include/vtts_nat.h); PyTorch-ROCm only
+provides device memory and the stream.  There is no CPU path.
+
+The prenet's dropout is on at inference in the reference (model.py:95-100) and draws from JAX's threefry PRNG through
+Haiku's per-scan-step key splitting; that stream is not restated here.  ``keep_masks`` (boolean ``[n_frames, 2, 256]`` per
+sentence) makes the dropout explicit; ``None`` runs without dropout.  :func:`bernoulli_keep_masks` draws reproducible masks
+from numpy's PCG64 (rate 0.5, the reference's rate) — statistically, not bitwise, the reference's behaviour.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .config import FLAGS
+from .duration import HaikuDict, _lookup, _ptr
+
+
+def bernoulli_keep_masks(n_frames: int, seed: int, prenet_dim: int = 256) -> np.ndarray:
+    """``[n_frames, 2, prenet_dim]`` boolean keep masks, P(keep) = 0.5 (hk.dropout(key, 0.5, x), model.py:97, :99)."""
+    return np.random.default_rng(seed).random((n_frames, 2, prenet_dim)) >= 0.5
+
+
+class AcousticModel:
+    def __init__(self, device="cuda:0", lib_path=None, vocab_size: int = FLAGS.vocab_size, encoder_dim: int = FLAGS.acoustic_encoder_dim,
+                 decoder_dim: int = FLAGS.acoustic_decoder_dim, prenet_dim: int = 256, mel_dim: int = FLAGS.mel_dim, postnet_dim: int = FLAGS.postnet_dim):
+        self.lib = _lib.load(lib_path)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("AcousticModel needs a ROCm device ('cuda:N'); there is no CPU path")
+        self.cfg = _lib.NatAcousticCfg(vocab_size, encoder_dim, decoder_dim, prenet_dim, mel_dim, postnet_dim)
+        self.mel_dim, self.prenet_dim = mel_dim, prenet_dim
+        self._h = C.c_void_p(0)
+        dev_index = self.device.index if self.device.index is not None else 0
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_create(C.byref(self.cfg), dev_index, C.byref(self._h)))
+        self._blob: Optional[torch.Tensor] = None
+        self._ws: Optional[torch.Tensor] = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.vtts_nat_acoustic_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def param_table(self):
+        n = C.c_int(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_num_params(self._h, C.byref(n)))
+        out = []
+        for i in range(n.value):
+            mod, name = C.c_char_p(), C.c_char_p()
+            shape = (C.c_int64 * 3)()
+            nd = C.c_int(0)
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_param_info(self._h, i, C.byref(mod), C.byref(name), shape, C.byref(nd)))
+            out.append((mod.value.decode(), name.value.decode(), tuple(int(shape[d]) for d in range(nd.value))))
+        return out
+
+    def load_params(self, params: HaikuDict, state: HaikuDict) -> None:
+        """``dic["params"]`` and ``dic["aux"]`` of acoustic_latest_ckpt.pickle (text2mel.py:62-71)."""
+        for mod, name, shape in self.param_table():
+            a = _lookup(state if name == "average" else params, "acoustic_model/~/" + mod, name)
+            if a.shape != shape:
+                raise ValueError(f"{mod}/{name}: checkpoint shape {a.shape}, the architecture needs {shape}")
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_set_param(self._h, mod.encode(), name.encode(), a.ctypes.data_as(C.c_void_p), shp, a.ndim))
+        n = C.c_size_t(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_packed_bytes(self._h, C.byref(n)))
+        blob = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_pack(self._h, _ptr(blob), blob.numel(), C.c_void_p(stream.cuda_stream)))
+        self._blob = blob
+
+    def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
+                 keep_masks: Optional[Sequence[np.ndarray]] = None) -> List[np.ndarray]:
+        """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``."""
+        if self._blob is None:
+            raise RuntimeError("no parameters loaded")
+        B = len(sentences)
+        lens = [len(s) for s in sentences]
+        if B == 0 or min(lens) < 1 or min(n_frames) < 1:
+            raise ValueError("empty batch, token sequence or frame count")
+        Lmax, Fmax = max(lens), int(max(n_frames))
+        tok = np.zeros((B, Lmax), dtype=np.int32)
+        dur = np.zeros((B, Lmax), dtype=np.float32)
+        for i, s in enumerate(sentences):
+            tok[i, : lens[i]] = np.asarray(s, dtype=np.int32)
+            dur[i, : lens[i]] = np.asarray(durations_frames[i], dtype=np.float32).reshape(-1)
+        keep_d = None
+        if keep_masks is not None:
+            keep = np.zeros((B, Fmax, 2, self.prenet_dim), dtype=np.uint8)
+            for i, m in enumerate(keep_masks):
+                keep[i, : n_frames[i]] = np.asarray(m, dtype=bool)[: n_frames[i]]
+            keep_d = torch.from_numpy(keep).to(self.device)
+        tok_d = torch.from_numpy(tok).to(self.device)
+        dur_d = torch.from_numpy(dur).to(self.device)
+        len_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        nf_d = torch.tensor([int(n) for n in n_frames], dtype=torch.int32, device=self.device)
+        out = torch.empty((B, Fmax, self.mel_dim), dtype=torch.float32, device=self.device)
+        n = C.c_size_t(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_workspace_bytes(self._h, B, Lmax, Fmax, C.byref(n)))
+        if self._ws is None or self._ws.numel() < n.value:
+            self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib,
+                self.lib.vtts_nat_acoustic_forward(self._h, _ptr(tok_d), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d), _ptr(out),
+                                                   _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream)),
+            )
+        host = out.cpu().numpy()
+        return [host[i, : n_frames[i]].copy() for i in range(B)]

@@ -10,6 +10,9 @@ class FLAGS:
     # model dimensions (config.py:11-17)
     duration_lstm_dim = 256
     vocab_size = 256
+    postnet_dim = 512
+    acoustic_decoder_dim = 512
+    acoustic_encoder_dim = 256
     # Montreal-Forced-Aligner specials: [sil] [sp] [spn] [word end]   (config.py:24-27)
     special_phonemes = ["sil", "sp", "spn", " "]
     sil_index = 0

@@ -35,3 +35,46 @@ def synthetic_duration_checkpoint(seed: int = 777, vocab_size: int = FLAGS.vocab
     P["duration_model/~/linear"] = {"w": n(2 * dim, dim, scale=(1.0 / (2 * dim)) ** 0.5 * 3.0), "b": n(dim, scale=0.05)}
     P["duration_model/~/linear_1"] = {"w": n(dim, 1, scale=(1.0 / dim) ** 0.5 * 2.0), "b": np.array([-2.0], f32)}
     return P, S
+
+
+def synthetic_acoustic_checkpoint(seed: int = 778, vocab_size: int = FLAGS.vocab_size, enc: int = FLAGS.acoustic_encoder_dim,
+                                  dec: int = FLAGS.acoustic_decoder_dim, prenet: int = 256, mel: int = FLAGS.mel_dim,
+                                  post: int = FLAGS.postnet_dim) -> Tuple[HaikuDict, HaikuDict]:
+    """Haiku-layout ``params`` / ``state`` of AcousticModel (model.py:76-93) with seeded values; scales keep the
+    autoregressive loop stable (mel outputs O(1), LSTM pre-activations O(1))."""
+    g = np.random.default_rng(seed)
+    f32 = np.float32
+
+    def n(*shape, scale=1.0):
+        return (g.standard_normal(shape) * scale).astype(f32)
+
+    P: HaikuDict = {}
+    S: HaikuDict = {}
+
+    def bn(path, C):
+        P[path] = {"scale": (1.0 + n(1, 1, C, scale=0.1)).astype(f32), "offset": n(1, 1, C, scale=0.1)}
+        S[path + "/~/mean_ema"] = {"average": n(1, 1, C, scale=0.2), "hidden": n(1, 1, C), "counter": np.array(1000, np.int32)}
+        S[path + "/~/var_ema"] = {"average": (1.0 + np.abs(n(1, 1, C, scale=0.3))).astype(f32), "hidden": n(1, 1, C), "counter": np.array(1000, np.int32)}
+
+    te = "acoustic_model/~/token_encoder/~/"
+    P[te + "embed"] = {"embeddings": n(vocab_size, enc)}
+    for i in range(3):
+        sfx = f"_{i}" if i else ""
+        P[te + "conv1_d" + sfx] = {"w": n(3, enc, enc, scale=(2.0 / (3 * enc)) ** 0.5), "b": n(enc, scale=0.05)}
+        bn(te + "batch_norm" + sfx, enc)
+    for l in ("lstm", "lstm_1"):
+        P[te + l + "/linear"] = {"w": n(2 * enc, 4 * enc, scale=(1.0 / (2 * enc)) ** 0.5), "b": n(4 * enc, scale=0.05)}
+    X = 2 * enc + prenet
+    pre = "acoustic_model/~/"
+    P[pre + "lstm/linear"] = {"w": n(X + dec, 4 * dec, scale=(1.0 / (X + dec)) ** 0.5), "b": n(4 * dec, scale=0.05)}
+    P[pre + "lstm_1/linear"] = {"w": n(dec + X + dec, 4 * dec, scale=(1.0 / (2 * dec + X)) ** 0.5), "b": n(4 * dec, scale=0.05)}
+    P[pre + "linear"] = {"w": n(2 * dec, mel, scale=(1.0 / (2 * dec)) ** 0.5 * 2.0), "b": n(mel, scale=0.1)}
+    P[pre + "linear_1"] = {"w": n(mel, prenet, scale=(2.0 / mel) ** 0.5)}
+    P[pre + "linear_2"] = {"w": n(prenet, prenet, scale=(2.0 / prenet) ** 0.5)}
+    for i in range(5):
+        sfx = f"_{i}" if i else ""
+        cin, cout = (mel if i == 0 else post), (mel if i == 4 else post)
+        P[pre + "conv1_d" + sfx] = {"w": n(5, cin, cout, scale=(1.0 / (5 * cin)) ** 0.5), "b": n(cout, scale=0.05)}
+        if i < 4:
+            bn(pre + "batch_norm" + sfx, post)
+    return P, S

@@ -10,10 +10,15 @@ What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
   * ``predict_duration(tokens)`` (:22-34) on the MI355X: the NAT duration model (vietTTS/nat/model.py:9-70) runs in
     the HIP library behind include/vtts_nat.h (viettts_amd/nat/duration.py); there is no CPU path.
 
-What is NOT built yet: the NAT acoustic network (vietTTS/nat/model.py:73-171 — autoregressive 2xLSTM decoder with
-always-on prenet dropout driven by JAX's threefry PRNG).  ``text2mel`` therefore raises ``NotImplementedError``
-unless a mel provider has been registered with :func:`set_mel_provider` (tests and the CLI's ``--mel-file`` use
-that hook).
+  * ``predict_mel(tokens, durations)`` (:61-82) on the MI355X: the acoustic network's inference path
+    (vietTTS/nat/model.py:128-151) behind the same header (viettts_amd/nat/acoustic.py).  The reference's prenet
+    dropout is ON at inference and draws from JAX's threefry PRNG with the checkpoint's key; that stream is not
+    restated: ``predict_mel`` draws its keep masks (rate 0.5) from numpy's PCG64 seeded by ``dropout_seed`` —
+    statistically, not bitwise, the reference's mel.
+
+``text2mel`` uses a registered mel provider (:func:`set_mel_provider`; tests and the CLI's ``--mel-file``) if there is
+one, else the two networks, loading ``duration_latest_ckpt.pickle`` / ``acoustic_latest_ckpt.pickle`` from
+``FLAGS.ckpt_dir`` on first use (``FileNotFoundError`` if absent, as in the reference).
 """
 from __future__ import annotations
 
@@ -125,6 +130,50 @@ def predict_duration(tokens: Sequence[int]) -> np.ndarray:
     return _DURATION_MODEL([list(tokens)])[0][None, :]
 
 
+_ACOUSTIC_MODEL = None
+
+
+def set_acoustic_model(model) -> None:
+    """Install a loaded :class:`viettts_amd.nat.acoustic.AcousticModel` for :func:`predict_mel`."""
+    global _ACOUSTIC_MODEL
+    _ACOUSTIC_MODEL = model
+
+
+def load_acoustic_checkpoint(path=None):
+    """``dic["params"], dic["aux"]`` of ``acoustic_latest_ckpt.pickle`` (text2mel.py:62-71)."""
+    import pickle
+
+    path = FLAGS.ckpt_dir / "acoustic_latest_ckpt.pickle" if path is None else path
+    with open(path, "rb") as f:
+        dic = pickle.load(f)
+    to_np = lambda d: {k: {n: np.asarray(a) for n, a in dict(v).items()} for k, v in dict(d).items()}
+    return to_np(dic["params"]), to_np(dic["aux"])
+
+
+def predict_mel(tokens: Sequence[int], durations: np.ndarray, dropout_seed: Optional[int] = 0) -> np.ndarray:
+    """Reference signature and result (text2mel.py:61-82): ``durations`` float32 ``[1, L]`` in SECONDS -> mel
+    ``[1, n_frames, 80]`` with ``n_frames = int(sum(durations * sample_rate / hop))``.  ``dropout_seed=None`` turns the
+    prenet dropout off (deterministic; not what the reference does)."""
+    global _ACOUSTIC_MODEL
+    if _ACOUSTIC_MODEL is None:
+        from .acoustic import AcousticModel
+
+        params, state = load_acoustic_checkpoint()
+        m = AcousticModel()
+        m.load_params(params, state)
+        _ACOUSTIC_MODEL = m
+    frames = durations_to_frames(durations)  # :78
+    n_frames = n_frames_from_durations(durations)  # :79
+    if n_frames < 1:
+        return np.zeros((1, 0, FLAGS.mel_dim), dtype=np.float32)
+    keep = None
+    if dropout_seed is not None:
+        from .acoustic import bernoulli_keep_masks
+
+        keep = [bernoulli_keep_masks(n_frames, dropout_seed)]
+    return _ACOUSTIC_MODEL([list(tokens)], [frames[0]], [n_frames], keep_masks=keep)[0][None]
+
+
 _MEL_PROVIDER: Optional[Callable] = None
 
 
@@ -138,12 +187,15 @@ def set_mel_provider(fn: Optional[Callable]) -> None:
 def text2mel(text: str, lexicon_fn=FLAGS.data_dir / "lexicon.txt", silence_duration: float = -1.0):
     """Reference signature (text2mel.py:85-87).  Returns ``[1, T, 80]`` float32 log-mel."""
     tokens = text2tokens(text, lexicon_fn)
-    if _MEL_PROVIDER is None:
-        raise NotImplementedError(
-            "the NAT duration/acoustic networks are not built yet (SURVEY.md §8f ranks 2-3); "
-            "register a mel provider with viettts_amd.nat.text2mel.set_mel_provider() or use the CLI's --mel-file"
-        )
-    mel = np.asarray(_MEL_PROVIDER(tokens, lexicon_fn, silence_duration), dtype=np.float32)
-    if mel.ndim != 3 or mel.shape[0] != 1 or mel.shape[2] != FLAGS.mel_dim:
-        raise ValueError(f"mel provider returned shape {mel.shape}, expected [1, T, {FLAGS.mel_dim}]")
-    return mel
+    if _MEL_PROVIDER is not None:
+        mel = np.asarray(_MEL_PROVIDER(tokens, lexicon_fn, silence_duration), dtype=np.float32)
+        if mel.ndim != 3 or mel.shape[0] != 1 or mel.shape[2] != FLAGS.mel_dim:
+            raise ValueError(f"mel provider returned shape {mel.shape}, expected [1, T, {FLAGS.mel_dim}]")
+        return mel
+    durations = predict_duration(tokens)  # :89
+    durations = apply_duration_rules(tokens, durations, silence_duration)  # :90-97
+    mels = predict_mel(tokens, durations)  # :98
+    if tokens[-1] == FLAGS.sil_index:  # :99-102
+        silence_frame = trailing_silence_frames(durations)
+        mels = mels[:, : (mels.shape[1] - silence_frame)]
+    return mels
