@@ -253,6 +253,23 @@ def main():
                 "rtf_22050": med / (131072 / 22050.0),
             }
             g32.close()
+        # ---- long-form (BASELINE configs[4]): 10 min of 16 kHz audio, exact 512-frame chunks + 13-frame halo ----
+        if not args.no_rtf:
+            from viettts_amd.longform import synthesize_chunked
+
+            T10 = 37500  # 600 s * 16000 / 256
+            m10 = torch.from_numpy(synthetic_mel(1, T10, 99)[0]).to(dev)
+            synthesize_chunked(gen, m10[:2048], 512)  # warm-up of the chunk shapes
+            torch.cuda.synchronize()
+            tm = {}
+            synthesize_chunked(gen, m10, 512, timing=tm)
+            res["longform_10min"] = {
+                "workload": "one 37500-frame utterance (600 s @16 kHz), 512-frame chunks + 13-frame halo, 16 chunks per batch, this GPU only",
+                "first_chunk_ms": tm["first_chunk_s"] * 1e3,
+                "total_ms": tm["total_s"] * 1e3,
+                "rtf_16000": tm["total_s"] / 600.0,
+                "chunks": tm["chunks"],
+            }
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
