@@ -174,22 +174,28 @@ def test_bf16_taps_vs_oracle(gen, v1_params, dev):
 
 
 @pytest.mark.parametrize("T", [1, 3, 37, 300], ids=lambda t: f"T{t}")
-def test_fused_resblock32_equals_pair_path(gen, dev, T):
-    """The whole-ResBlock kernel of the C = 32 stage (fuse = 2) against the pair-by-pair path (fuse = 1): same operands,
-    same bf16 rounding points, only fp32 summation order (bias first vs last) differs -> a few output ulps.  T = 1, 3:
-    utterances shorter than every halo; 37, 300: several ragged 392..488-column windows, both utterance edges."""
+def test_fused_resblock_equals_pair_path(gen, dev, T):
+    """The whole-ResBlock kernels (C = 32: k = 3, 7, 11; C = 64, 128: k = 3) against the pair-by-pair path (fuse = 1): same
+    operands, same bf16 rounding points, only fp32 summation order differs -> a few output ulps.  T = 1, 3: utterances
+    shorter than every halo; 37, 300: several ragged windows, both utterance edges.  Checked at every stage that has a
+    fused ResBlock (taps mrf_1: C = 128, mrf_2: C = 64, mrf_3: C = 32) and at the waveform."""
     mel = torch.from_numpy(synthetic_mel(2, T, 31 + T)).to(dev)
     out = {}
-    for fuse in (3, 2, 1):  # 3: the ResBlock kernel for k = 3, 7, 11; 2: for k = 3, 7 (the default); 1: pairs only
+    for fuse in (3, 2, 1):  # 3: the ResBlock kernel wherever it exists; 2: where it is the faster choice (default); 1: pairs only
         gen.set_option("fuse", fuse)
-        wav, tap = gen.forward_tap(mel, "mrf_3")
-        torch.cuda.synchronize()
-        out[fuse] = (wav.cpu().numpy().copy(), tap.cpu().numpy().copy())
+        out[fuse] = {}
+        for tap in ("mrf_1", "mrf_2", "mrf_3"):
+            wav, t = gen.forward_tap(mel, tap)
+            torch.cuda.synchronize()
+            out[fuse][tap] = t.cpu().numpy().copy()
+        out[fuse]["wav"] = wav.cpu().numpy().copy()
     gen.set_option("fuse", 2)
-    ref = out[1][1]
     for fuse in (3, 2):
-        assert np.abs(out[fuse][1] - ref).max() <= 2.0 ** -6 * np.abs(ref).max(), (fuse, np.abs(out[fuse][1] - ref).max(), np.abs(ref).max())
-        assert np.abs(out[fuse][0] - out[1][0]).max() < 0.02
+        for tap in ("mrf_1", "mrf_2", "mrf_3"):
+            ref = out[1][tap]
+            err = np.abs(out[fuse][tap] - ref).max()
+            assert err <= 2.0 ** -6 * np.abs(ref).max(), (fuse, tap, err, np.abs(ref).max())
+        assert np.abs(out[fuse]["wav"] - out[1]["wav"]).max() < 0.02
 
 
 def test_bf16_batch_and_microbatch_invariance(gen, dev):

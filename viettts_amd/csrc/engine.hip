@@ -74,7 +74,7 @@ struct Layer {
     // fused pair (this layer = convs1_z, next layer = convs2_z): [c1 slabs][c2 slabs] + [b1][b2]
     bool has_pair = false;
     size_t off_pw = 0, pw_bytes = 0, off_pb = 0;
-    // whole ResBlock (this layer = convs1_0 of a C = 32 ResBlock): six convolutions' slabs + six biases
+    // whole ResBlock (this layer = convs1_0 of a ResBlock with a fused kernel): six convolutions' fragments + six biases
     bool has_rb = false;
     size_t off_rw = 0, rw_bytes = 0, off_rb = 0;
 };
@@ -190,7 +190,7 @@ int build_layers_bf16(vtts_hifigan* h) {
     for (size_t r = 0; r < h->idx_res.size(); ++r) {
         Layer& c0 = h->layers[h->idx_res[r]];
         const int dils[3] = {h->layers[h->idx_res[r] + 0].dil, h->layers[h->idx_res[r] + 2].dil, h->layers[h->idx_res[r] + 4].dil};
-        bool ok = resblock32_bf16_supported(c0.cin, c0.k, dils);
+        bool ok = resblock_bf16_supported(c0.cin, c0.k, dils);
         for (int q = 0; q < 6 && ok; ++q) {
             const Layer& l = h->layers[h->idx_res[r] + q];
             ok = l.cin == c0.cin && l.cout == c0.cin && l.k == c0.k && ((q & 1) ? l.dil == 1 : true);
@@ -457,7 +457,7 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     return VTTS_OK;
 }
 
-int run_resblock32_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, int L, float slope_out, void* y, int acc_add, float div,
+int run_resblock_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, int L, float slope_out, void* y, int acc_add, float div,
                         hipStream_t s) {
     BConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -476,7 +476,7 @@ int run_resblock32_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, 
     a.slope_out = slope_out;
     a.acc_add = acc_add;
     a.div = div;
-    hipError_t e = launch_resblock32_bf16(rb[0].k, a, s);
+    hipError_t e = launch_resblock_bf16(rb[0].cin, rb[0].k, a, s);
     if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused ResBlock launch for %s failed: %s", rb[0].key.c_str(), hipGetErrorString(e));
     return VTTS_OK;
 }
@@ -609,11 +609,10 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 const int base = h->idx_res[i * nk + j];
                 const char* cur = bufX;
                 const bool last_rb = (j == nk - 1);
-                // measured (profiles/r01_f_*): the whole-ResBlock kernel wins for k = 3, 7 (1.25 / 2.21 ms vs 1.83 / 2.56 ms as
-                // three pairs) and loses slightly for k = 11 (3.44 vs 3.28 ms: 23 % of its window is halo); fuse = 3 forces it
-                if (h->opt_fuse >= 2 && h->layers[base].has_rb && (h->opt_fuse >= 3 || h->layers[base].k < 11)) {
+                // the whole-ResBlock kernel where it exists and is the faster choice (fuse = 3: wherever it exists)
+                if (h->opt_fuse >= 2 && h->layers[base].has_rb && (h->opt_fuse >= 3 || resblock_bf16_preferred(h->layers[base].cin, h->layers[base].k))) {
                     // the whole ResBlock in one kernel: X -> S (store / accumulate / accumulate-and-divide)
-                    rc = run_resblock32_bf16(h, &h->layers[base], cur, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
+                    rc = run_resblock_bf16(h, &h->layers[base], cur, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
                                              last_rb ? (float)nk : 1.0f, s);
                     if (rc) return rc;
                     continue;

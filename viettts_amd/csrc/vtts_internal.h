@@ -110,10 +110,11 @@ const char* pair_g_kernel_name(int C, int K);
 hipError_t launch_pair_lds_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 BPackGeom pair_lds_pack_geom(int C, int K);
 const char* pair_lds_kernel_name(int C, int K);
-// whole ResBlock1 of the C = 32 stage in one kernel (kernels_bf16_rb32.hip)
-bool resblock32_bf16_supported(int C, int K, const int* dils);
-hipError_t launch_resblock32_bf16(int K, const BConvArgs& a, hipStream_t s);
-const char* resblock32_kernel_name(int K);
+// whole ResBlock1 in one kernel (kernels_bf16_rbk.hip): C = 32 (k = 3, 7, 11), C = 64 / 128 (k = 3)
+bool resblock_bf16_supported(int C, int K, const int* dils);
+bool resblock_bf16_preferred(int C, int K);
+hipError_t launch_resblock_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+const char* resblock_kernel_name(int C, int K);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
