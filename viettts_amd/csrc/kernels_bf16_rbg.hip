@@ -16,6 +16,8 @@
 //   * LDS holds only the activation tile (<= 78 KiB), so two 4-wave workgroups share a CU; nothing couples their phases.
 //     C = 256: 128-column tiles, the X tile staged 128 input channels at a time (2 x 45 KiB), the xt tile 69 KiB.
 // s_barrier remains at the three tile-level hand-offs (X staged / X dead / xt written).
+// Tried and measured no better (tools/kbench, round 1): 32 x 128 wave tiles with three workgroups per CU (LDS read traffic per
+// MFMA doubles), a 7-deep weight ring, 8-wave workgroups.
 #include <stdio.h>
 #include <string.h>
 
