@@ -138,7 +138,8 @@ int main(int argc, char** argv) {
     a.y = dy;
     a.B = B;
     a.L = L;
-    a.x_pitch = impl == 0 ? C : stagger;
+    a.x_pitch = C;
+    (void)stagger;
     a.cin_real = C | (dflags << 16);
     a.dil = dil;
     a.pad = (K - 1) / 2 * dil;

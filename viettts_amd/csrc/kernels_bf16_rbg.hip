@@ -17,7 +17,7 @@
 //     C = 256: 128-column tiles, the X tile staged 128 input channels at a time (2 x 45 KiB), the xt tile 69 KiB.
 // s_barrier remains at the three tile-level hand-offs (X staged / X dead / xt written).
 // Tried and measured no better (tools/kbench, round 1): 32 x 128 wave tiles with three workgroups per CU (LDS read traffic per
-// MFMA doubles), a 7-deep weight ring, 8-wave workgroups.
+// MFMA doubles), a 7-deep weight ring, 8-wave workgroups, a forced start offset between a CU's two workgroups (0 .. 100k cycles).
 #include <stdio.h>
 #include <string.h>
 
