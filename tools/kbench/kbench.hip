@@ -92,9 +92,9 @@ int main(int argc, char** argv) {
     int dflags = 0, stagger = 0;
     if (argc > 9) stagger = atoi(argv[9]);  // kernels_bf16_rb.hip: start offset (shader cycles) of a CU's second workgroup
     if (argc > 8) dflags = atoi(argv[8]);  // timeline builds of kernels_bf16_rb.hip: experiment switches (results wrong)
-    if (argc > 7) impl = atoi(argv[7]);  // 0 = kernels_bf16_pair.hip (LDS-staged weights), 30 = kernels_bf16_rbg.hip
+    if (argc > 7) impl = atoi(argv[7]);  // kept for old command lines; there is one pair kernel (kernels_bf16_rbg.hip)
     printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
-    auto launch = [&](const BConvArgs& aa) { return impl == 0 ? launch_pair_lds_bf16(C, K, aa, 0) : launch_pair_g_bf16(C, K, aa, 0); };
+    auto launch = [&](const BConvArgs& aa) { return launch_pair_g_bf16(C, K, aa, 0); };
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     const size_t n = (size_t)B * L * C;
@@ -105,7 +105,7 @@ int main(int argc, char** argv) {
     for (auto& v : w1) v = bf2f(f2bf(ws * nd(rng)));
     for (auto& v : w2) v = bf2f(f2bf(ws * nd(rng)));
     for (auto& v : bias) v = 0.1f * nd(rng);
-    const BPackGeom g = impl == 0 ? pair_lds_pack_geom(C, K) : pair_g_pack_geom(C, K);
+    const BPackGeom g = pair_g_pack_geom(C, K);
     const size_t pb = bf16_packed_bytes(g);
     std::vector<unsigned short> wp(pb);  // 2 * pb bytes
     bf16_pack(w1.data(), C, g, wp.data());

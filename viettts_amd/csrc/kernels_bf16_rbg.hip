@@ -89,30 +89,62 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 
     // Accumulators start from the bias (row = channel 32*mr + 8*rq + 4*lh + i of this wave's m-block, r = 4*rq + i)
     f32x16 acc[MR][NR];
-    auto init_acc = [&](const float* __restrict__ bias) {
+    float4 bq[MR][4];
+    auto load_bias = [&](const float* __restrict__ bias) {  // requested a phase ahead of the MFMAs that consume it
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias + wm * (C / T::WM) + mr * 32 + 8 * rq + 4 * lh);
+            for (int rq = 0; rq < 4; ++rq) bq[mr][rq] = *reinterpret_cast<const float4*>(bias + wm * (C / T::WM) + mr * 32 + 8 * rq + 4 * lh);
+    };
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    acc[mr][nr][4 * rq + 0] = bv.x;
-                    acc[mr][nr][4 * rq + 1] = bv.y;
-                    acc[mr][nr][4 * rq + 2] = bv.z;
-                    acc[mr][nr][4 * rq + 3] = bv.w;
+                    acc[mr][nr][4 * rq + 0] = bq[mr][rq].x;
+                    acc[mr][nr][4 * rq + 1] = bq[mr][rq].y;
+                    acc[mr][nr][4 * rq + 2] = bq[mr][rq].z;
+                    acc[mr][nr][4 * rq + 3] = bq[mr][rq].w;
                 }
-            }
     };
+    load_bias(a.bias);
 
     // ---------------- X tile (channel chunk xc): LeakyReLU + zero padding in registers, swizzled ds_write_b128 ----------------
     // XB = loads in flight per thread: all of them for the first chunk (nothing else is live yet), a few at a time for
     // a later chunk (the accumulators are live: 128 VGPRs)
     auto stage_x = [&](int xc, auto xb_tag) {
         constexpr int XB = decltype(xb_tag)::value;
+        constexpr int RPI = THREADS / SPR1;  // tile rows between a thread's consecutive 16-byte units
+        static_assert(THREADS % SPR1 == 0 && RPI % 16 == 0, "a thread's units share their column and their swizzle");
         const int nunits = rowsx * SPR1;
         const int tx0 = t0 - H2 - h1;
+        const int row0 = tid / SPR1, c = tid % SPR1;
         auto act2 = [](unsigned u) { return pack_bf16x2(lrelu01(bf16_lo(u)), lrelu01(bf16_hi(u))); };  // LRELU_SLOPE, model.py:5,46
+        unsigned char* const lds0 = xt + row0 * P1 + ((c ^ swz_of<SPR1>(row0)) << 4);  // unit i: + i * RPI * P1 (same swizzle)
+        if (tx0 >= 0 && tx0 + XPT * RPI <= L) {
+            // interior tile (all but the first / last of an utterance): no clamping, no masking, constant strides
+            const unsigned short* __restrict__ g0 = xg + (size_t)(tx0 + row0) * C + xc * XC + c * 8;
+#pragma unroll
+            for (int i0 = 0; i0 < XPT; i0 += XB) {
+                uint4 v[XB];
+#pragma unroll
+                for (int i = 0; i < XB; ++i)
+                    if (i0 + i < XPT) v[i] = *reinterpret_cast<const uint4*>(g0 + (size_t)(i0 + i) * RPI * C);
+#pragma unroll
+                for (int i = 0; i < XB; ++i) {
+                    v[i].x = act2(v[i].x);
+                    v[i].y = act2(v[i].y);
+                    v[i].z = act2(v[i].z);
+                    v[i].w = act2(v[i].w);
+                }
+#pragma unroll
+                for (int i = 0; i < XB; ++i)
+                    if (i0 + i < XPT && row0 + (i0 + i) * RPI < rowsx) *reinterpret_cast<uint4*>(lds0 + (i0 + i) * RPI * P1) = v[i];
+            }
+            return;
+        }
 #pragma unroll
         for (int i0 = 0; i0 < XPT; i0 += XB) {
             uint4 v[XB];
@@ -122,8 +154,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
             for (int i = 0; i < XB; ++i) {
                 const int u = tid + (i0 + i) * THREADS;
-                const int row = u / SPR1, c = u % SPR1;
-                const int t = tx0 + row;
+                const int t = tx0 + row0 + (i0 + i) * RPI;
                 okx[i] = i0 + i < XPT && u < nunits && t >= 0 && t < L;
                 const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
                 v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + xc * XC + c * 8);
@@ -137,15 +168,12 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 v[i].w = act2(v[i].w);
             }
 #pragma unroll
-            for (int i = 0; i < XB; ++i) {
-                const int u = tid + (i0 + i) * THREADS;
-                const int row = u / SPR1, c = u % SPR1;
-                if (i0 + i < XPT && u < nunits) *reinterpret_cast<uint4*>(xt + row * P1 + ((c ^ swz_of<SPR1>(row)) << 4)) = v[i];
-            }
+            for (int i = 0; i < XB; ++i)
+                if (i0 + i < XPT && row0 + (i0 + i) * RPI < rowsx) *reinterpret_cast<uint4*>(lds0 + (i0 + i) * RPI * P1) = v[i];
         }
     };
     stage_x(0, std::integral_constant<int, XPT>{});
-    init_acc(a.bias);
+    init_acc();
     __syncthreads();  // B1: X tile staged
     VTTS_TL(a, wg_lin, 1);
 
@@ -241,6 +269,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     };
 
     // ---------------- epilogue 1: LeakyReLU(0.1), bf16, zero outside [0, L) -> xt tile in LDS ----------------
+    load_bias(a.bias + C);  // c2's bias: lands while epilogue 1 runs
     {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -271,7 +300,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             *reinterpret_cast<uint4*>(xt + row * P2 + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    init_acc(a.bias + C);
+    init_acc();
     __syncthreads();  // B3: xt tile written
     VTTS_TL(a, wg_lin, 3);
 
@@ -398,15 +427,14 @@ const char* pair_g_kernel_name(int C, int K) {
     return buf;
 }
 
-// ---- the fused-pair entry points the engine uses: which generation runs which channel count ----------------------
+// ---- the fused-pair entry points the engine uses ---------------------------------------------------------------------
+// (the first generation — weight slabs double-buffered through LDS, one s_barrier per slab, kernels_bf16_pair.hip in the
+// history — lost to this one at every channel count once the tile staging here got its interior fast path)
 bool pair_bf16_supported(int C, int K, int dil) {
     return (C == 256 || C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5;
 }
-static bool pair_uses_g(int C) { return C == 256 || C == 128 || C == 64; }  // measured per class with tools/kbench (profiles/r01_e_*)
-BPackGeom pair_pack_geom(int C, int K) { return pair_uses_g(C) ? pair_g_pack_geom(C, K) : pair_lds_pack_geom(C, K); }
-hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
-    return pair_uses_g(C) ? launch_pair_g_bf16(C, K, a, s) : launch_pair_lds_bf16(C, K, a, s);
-}
-const char* pair_kernel_name(int C, int K) { return pair_uses_g(C) ? pair_g_kernel_name(C, K) : pair_lds_kernel_name(C, K); }
+BPackGeom pair_pack_geom(int C, int K) { return pair_g_pack_geom(C, K); }
+hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s) { return launch_pair_g_bf16(C, K, a, s); }
+const char* pair_kernel_name(int C, int K) { return pair_g_kernel_name(C, K); }
 
 }  // namespace vtts

@@ -20,7 +20,7 @@
 // whose time lies outside the utterance.  Weights: the six convolutions' A fragments are ONE continuous L2 -> register-ring
 // stream (as kernels_bf16_rbg.hip: no staging, no synchronisation inside the MFMA loops); two s_barriers per pair.
 //
-//   C = 32 : W = 512, waves 1 x 4, wave tile 32 x 128      used for k = 3, 7 (k = 11 exists; the pair kernel wins there)
+//   C = 32 : W = 512, waves 1 x 4, wave tile 32 x 128      used for k = 3 (k = 7, 11 exist; the pair kernel wins there)
 //   C = 64 : W = 256, waves 1 x 4, wave tile 64 x 64       used for k = 3
 //   C = 128: W = 128, waves 2 x 2, wave tile 64 x 64       exists for k = 3; the pair kernel wins there
 #include <stdio.h>
@@ -98,32 +98,33 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     }
     // ---- stage A = lrelu(x) over the window (zero outside the utterance) ----
     {
+        constexpr int RPI = THREADS / SPR;  // window rows between a thread's consecutive 16-byte units
+        static_assert(THREADS % SPR == 0 && RPI % 16 == 0 && (W * SPR) % THREADS == 0, "a thread's units share their column and their swizzle");
+        const int r0 = tid / SPR, c = tid % SPR;
+        unsigned char* const lds0 = tA + (GUARD + r0) * P + ((c ^ swz_of<SPR>(GUARD + r0)) << 4);  // unit i: + i * RPI * P
         uint4 v[XPT];
-        bool ok[XPT];
+        if (tw >= 0 && tw + W <= L) {  // interior window: no clamping, no masking, constant strides
+            const unsigned short* __restrict__ g0 = xg + (size_t)(tw + r0) * C + c * 8;
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int u = tid + i * THREADS;
-            const int r = u / SPR, c = u % SPR;
-            const int t = tw + r;
-            ok[i] = u < W * SPR && t >= 0 && t < L;
-            const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-            v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + c * 8);
+            for (int i = 0; i < XPT; ++i) v[i] = *reinterpret_cast<const uint4*>(g0 + (size_t)i * RPI * C);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {
+                const int t = tw + r0 + i * RPI;
+                const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+                v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + c * 8);
+                if (t < 0 || t >= L) v[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
         }
 #pragma unroll
         for (int i = 0; i < XPT; ++i) {
-            if (!ok[i]) v[i] = make_uint4(0u, 0u, 0u, 0u);
             v[i].x = act2(v[i].x);
             v[i].y = act2(v[i].y);
             v[i].z = act2(v[i].z);
             v[i].w = act2(v[i].w);
         }
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int u = tid + i * THREADS;
-            const int r = u / SPR, c = u % SPR;
-            const int row = GUARD + r;
-            if (u < W * SPR) *reinterpret_cast<uint4*>(tA + row * P + ((c ^ swz_of<SPR>(row)) << 4)) = v[i];
-        }
+        for (int i = 0; i < XPT; ++i) *reinterpret_cast<uint4*>(lds0 + i * RPI * P) = v[i];
     }
     // ---- the running x of this lane's outputs, in the accumulator layout, packed bf16: xr[mr][nr][p] = 8 values r0 = 8p ----
     // (column n = wn*(W/WN) + nr*32 + l31, channels cb0 + 32*mr + 8*rq + 4*lh + i for r = 4*rq + i)
@@ -379,11 +380,11 @@ bool resblock_bf16_supported(int C, int K, const int* dils) {
     if (C == 32) return K == 3 || K == 7 || K == 11;
     return (C == 64 || C == 128) && K == 3;
 }
-// ... and where it is the faster choice (measured per ResBlock at B = 64 x T = 1024, profiles/r01_g_*):
-//   C = 32 : k = 3  1.23 ms vs 1.83 ms as three pair launches;  k = 7  2.28 vs 2.56;  k = 11  3.44 vs 3.28 (23 % of the window is margin)
-//   C = 64 : k = 3  1.84 vs 2.36
-//   C = 128: k = 3  3.22 vs 3.19 (64 x 64 wave tiles double the weight-fragment traffic per MFMA; 19 % margin)
-bool resblock_bf16_preferred(int C, int K) { return (C == 32 && K != 11) || (C == 64 && K == 3); }
+// ... and where it is the faster choice (per ResBlock at B = 64 x T = 1024, rocprofv3, profiles/r01_h_fuse_policy.md):
+//   C = 32 : k = 3  1.21 ms vs 1.62 ms as three pair launches;  k = 7  2.27 vs 2.22;  k = 11  3.40 vs 3.08 (23 % of the window is margin)
+//   C = 64 : k = 3  1.77 vs 2.29
+//   C = 128: k = 3  3.23 vs 3.07 (64 x 64 wave tiles double the weight-fragment traffic per MFMA; 19 % margin)
+bool resblock_bf16_preferred(int C, int K) { return K == 3 && (C == 32 || C == 64); }
 
 // a.wp = [pair0 c1][pair0 c2][pair1 c1]...[pair2 c2], each one convolution in pair_g_pack_geom(C, K) order;
 // a.bias = 6 x [C]; a.dils = the three rates; a.x = stage input (raw), a.y = MRF accumulator / stage output

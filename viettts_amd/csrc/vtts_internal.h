@@ -95,21 +95,16 @@ BPackGeom bf16_pack_geom(int cls, int K);
 const char* bf16_kernel_name(int cls, int K);
 size_t bf16_packed_bytes(const BPackGeom& g);
 void bf16_pack(const float* Wc, int cin_real, const BPackGeom& g, unsigned short* out);
-// fused ResBlock1 pair (c1 -> lrelu -> c2 -> + x): kernels_bf16_pair.hip.  a.wp = [c1 slabs][c2 slabs],
+// fused ResBlock1 pair (c1 -> lrelu -> c2 -> + x): kernels_bf16_rbg.hip.  a.wp = [c1 fragments][c2 fragments],
 // a.bias = [b1 (C)][b2 (C)], a.x = raw pair input (also the residual), a.dil/a.pad = c1's rate / pad.
 bool pair_bf16_supported(int C, int K, int dil);
 BPackGeom pair_pack_geom(int C, int K);
 hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 const char* pair_kernel_name(int C, int K);
-// the two generations behind those entry points:
-//   kernels_bf16_rbg.hip   weights straight from L2 into register rings, no workgroup sync in the main loops (C = 128, 64)
-//   kernels_bf16_pair.hip  weight slabs double-buffered through LDS, one s_barrier per slab (C = 32)
+// kernels_bf16_rbg.hip: weights straight from L2 into register rings, no workgroup sync in the main loops
 hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 BPackGeom pair_g_pack_geom(int C, int K);
 const char* pair_g_kernel_name(int C, int K);
-hipError_t launch_pair_lds_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
-BPackGeom pair_lds_pack_geom(int C, int K);
-const char* pair_lds_kernel_name(int C, int K);
 // whole ResBlock1 in one kernel (kernels_bf16_rbk.hip): C = 32 (k = 3, 7, 11), C = 64 / 128 (k = 3)
 bool resblock_bf16_supported(int C, int K, const int* dils);
 bool resblock_bf16_preferred(int C, int K);
