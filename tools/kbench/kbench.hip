@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
     if (argc > 5) L = atoi(argv[5]);
     if (argc > 6) reps = atoi(argv[6]);
     int dflags = 0, stagger = 0;
-    if (argc > 9) stagger = atoi(argv[9]);  // kernels_bf16_rb.hip: start offset (shader cycles) of a CU's second workgroup
+    if (argc > 9) stagger = atoi(argv[9]);  // development builds with a start-offset switch (none in the tree now)
     if (argc > 8) dflags = atoi(argv[8]);  // timeline builds of kernels_bf16_rb.hip: experiment switches (results wrong)
     if (argc > 7) impl = atoi(argv[7]);  // kept for old command lines; there is one pair kernel (kernels_bf16_rbg.hip)
     printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
@@ -139,8 +139,7 @@ int main(int argc, char** argv) {
     a.B = B;
     a.L = L;
     a.x_pitch = C;
-    (void)stagger;
-    a.cin_real = C | (dflags << 16);
+    a.cin_real = C | ((dflags ? dflags : stagger) << 16);
     a.dil = dil;
     a.pad = (K - 1) / 2 * dil;
     a.slope_in = 0.1f;
@@ -213,16 +212,29 @@ int main(int argc, char** argv) {
             if (h[(size_t)i * 16 + 6]) nwg = i + 1;
         auto seg = [&](const char* nm, int from, int to) {
             double sm = 0;
-            for (int i = 0; i < nwg; ++i) sm += (double)(h[(size_t)i * 16 + to] - h[(size_t)i * 16 + from]);
-            printf("  %-34s %9.0f\n", nm, sm / nwg);
+            int cnt = 0;
+            for (int i = 0; i < nwg; ++i)
+                if (h[(size_t)i * 16 + to] && h[(size_t)i * 16 + from]) {  // edge tiles skip some stamps
+                    sm += (double)(h[(size_t)i * 16 + to] - h[(size_t)i * 16 + from]);
+                    ++cnt;
+                }
+            printf("  %-34s %9.0f\n", nm, cnt ? sm / cnt : 0.0);
         };
         printf("timeline over %d workgroups (shader-clock ticks, mean per workgroup; thread 0's view):\n", nwg);
         if (impl == 20 || impl >= 30) {
             seg("stage_x + barrier", 0, 1);
+            seg("   issue loads", 0, 7);
+            seg("   wait vmcnt(0)", 7, 8);
+            seg("   lrelu + ds_write", 8, 9);
+            seg("   init_acc + barrier", 9, 1);
             seg("c1 main loop", 1, 2);
             seg("B2 + epilogue 1 + B3", 2, 3);
             seg("c2 main loop", 3, 4);
             seg("epilogue 2", 4, 6);
+            seg("   issue residual loads", 4, 10);
+            seg("   wait vmcnt(0)", 10, 11);
+            seg("   add", 11, 12);
+            seg("   pack, swap, store", 12, 6);
             double sp = 0, st = 0;
             if (impl == 20)
             for (int i = 0; i < nwg; ++i) { sp += (double)h[(size_t)i * 16 + 11]; st += (double)h[(size_t)i * 16 + 12]; }
@@ -262,6 +274,27 @@ int main(int argc, char** argv) {
             printf("   later:");
             for (int i = 0; i < 16; ++i) if (rest[i]) printf("  slot%d:%d", i, rest[i]);
             printf("\n");
+        }
+        {  // one CU's workgroups in start order: phase stamps relative to the kernel's first stamp (lockstep or not?)
+            unsigned long long g0 = ~0ull;
+            for (int i = 0; i < nwg; ++i) g0 = std::min(g0, h[(size_t)i * 16 + 0]);
+            std::vector<int> ids;
+            const unsigned key0 = percu.begin()->first;
+            for (int i = 0; i < nwg; ++i) {
+                const unsigned long long id = h[(size_t)i * 16 + 15];
+                const unsigned hw = (unsigned)id, xcc = (unsigned)(id >> 32) & 0xf;
+                const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+                if (((xcc << 12) | (se << 8) | (sh << 4) | cu) == key0) ids.push_back(i);
+            }
+            std::sort(ids.begin(), ids.end(), [&](int x, int y) { return h[(size_t)x * 16] < h[(size_t)y * 16]; });
+            printf("one CU, workgroups in start order (ticks since kernel start): wg slot | start X-staged c1-done xt-written c2-done end\n");
+            for (size_t k = 0; k < ids.size() && k < 14; ++k) {
+                const int i = ids[k];
+                printf("  %6d s%llu |", i, h[(size_t)i * 16 + 15] & 0xf);
+                const int st[6] = {0, 1, 2, 3, 4, 6};
+                for (int q = 0; q < 6; ++q) printf(" %8llu", h[(size_t)i * 16 + st[q]] - g0);
+                printf("\n");
+            }
         }
         double busy = 0, span = 0, gaps = 0;
         long ngaps = 0;

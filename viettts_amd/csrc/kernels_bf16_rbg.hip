@@ -132,6 +132,13 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
                 for (int i = 0; i < XB; ++i)
                     if (i0 + i < XPT) v[i] = *reinterpret_cast<const uint4*>(g0 + (size_t)(i0 + i) * RPI * C);
+#if VTTS_TIMELINE
+                if (i0 == 0) {
+                    VTTS_TL(a, wg_lin, 7);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    VTTS_TL(a, wg_lin, 8);
+                }
+#endif
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
                     v[i].x = act2(v[i].x);
@@ -173,6 +180,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         }
     };
     stage_x(0, std::integral_constant<int, XPT>{});
+    VTTS_TL(a, wg_lin, 9);
     init_acc();
     __syncthreads();  // B1: X tile staged
     VTTS_TL(a, wg_lin, 1);
@@ -207,11 +215,22 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 for (int nr = 0; nr < NR; ++nr)
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][mr], bf[par][nr], acc[mr][nr], 0, 0, 0);
         };
-        // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers)
+        // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers), and spread
+        // them between the MFMAs: grouped issue (all loads, then all MFMAs) left the matrix pipe idle while a lone wave
+        // issued its 6 memory instructions (workgroup alone on a CU: 27.2k -> 26.0k cycles per 704-MFMA loop; whole
+        // forward +2.1 %, profiles/r01_j_kbench_findings.md)
         auto pin_step = [&](bool has_b) {
-            __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);       // VMEM reads: A fragments PA steps ahead
-            if (has_b) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);  // DS reads: B fragments of the next step
-            __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);  // MFMAs of this step
+            constexpr int NM = MR * NR;
+            const int mem = MR + (has_b ? NR : 0);
+            int done = 0;
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA of this step
+                const int upto = (i + 1) * mem / NM;
+                for (; done < upto; ++done) {
+                    if (done < MR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read: an A fragment PA steps ahead
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // DS read: a B fragment of the next step
+                }
+            }
         };
         static_assert(T::UNROLL_ALL || PA <= NKS, "look-ahead within two taps");
 #pragma unroll
@@ -326,6 +345,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                         const int tc = t < L ? t : L - 1;  // rows past the end are never stored: any in-bounds address will do
                         rv[mr][p][nr] = *reinterpret_cast<const uint4*>(src + (size_t)tc * C + wm * (C / T::WM) + mr * 32 + 16 * p + 8 * lh);
                     }
+#if VTTS_TIMELINE
+            VTTS_TL(a, wg_lin, 10);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            VTTS_TL(a, wg_lin, 11);
+#endif
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -344,6 +368,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         };
         add_rows(xg);                                                       // x = xt + x        (model.py:50)
         if (a.acc_add != 0) add_rows(yg);                                   // xs += rb(x)       (model.py:118-120)
+        VTTS_TL(a, wg_lin, 12);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -379,6 +404,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 
 // ---- tile table -------------------------------------------------------------------------------------
 //                                       C   KS   N1  WM WN PA MINWG
+#ifndef VTTS_EXP_LDS_PAD  // kernel-development switch (tools/kbench): extra LDS per workgroup, e.g. 20000 = one workgroup per CU
+#define VTTS_EXP_LDS_PAD 0
+#endif
 template <int KS> using G128 = GTile<128, KS, 256, 2, 2, 3, 2>;
 template <int KS> using G64 = GTile<64, KS, 512, 1, 4, 3, 2>;
 template <int KS> using G32 = GTile<32, KS, 512, 1, 4, 3, 2>;
@@ -388,13 +416,13 @@ static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_g_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           T::lds_bytes(T::MAXDIL));
+                                           T::lds_bytes(T::MAXDIL) + VTTS_EXP_LDS_PAD);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
     dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
-    hipLaunchKernelGGL(resblock_pair_g_bf16_k<T>, grid, dim3(T::THREADS), T::lds_bytes(a.dil), s, a);
+    hipLaunchKernelGGL(resblock_pair_g_bf16_k<T>, grid, dim3(T::THREADS), T::lds_bytes(a.dil) + VTTS_EXP_LDS_PAD, s, a);
     return hipGetLastError();
 }
 

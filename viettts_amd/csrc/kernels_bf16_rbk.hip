@@ -193,10 +193,19 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[(S0 + i) % RA][mr], bf[i & 1][nr], acc[mr][nr], 0, 0, 0);
-            // keep hipcc's scheduler from sinking the look-ahead loads to their uses
-            __builtin_amdgcn_sched_group_barrier(0x020, MR, 0);
-            if (has_b) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, MR * NR, 0);
+            // keep hipcc's scheduler from sinking the look-ahead loads to their uses, spread between the MFMAs
+            // (as in kernels_bf16_rbg.hip)
+            constexpr int NM = MR * NR;
+            const int mem = MR + (has_b ? NR : 0);
+            int done = 0;
+            for (int k = 0; k < NM; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                const int upto = (k + 1) * mem / NM;
+                for (; done < upto; ++done) {
+                    if (done < MR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         };
         constexpr int TAILQ = NQT % 4;  // 0 or 2 steps peeled after the rolled blocks of 4
         load_b(0, 0);
