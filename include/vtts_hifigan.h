@@ -117,6 +117,18 @@ int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, fl
                          void* workspace, size_t workspace_bytes, vtts_stream stream);
 
 /*
+ * forward() over utterances of DIFFERENT lengths in one batch (VTTS_BF16 handles): utterance b has frames_dev[b] mel
+ * frames (1 <= frames <= T) at the start of its [T, num_mels] slot.  Its first hop*frames[b] samples are exactly what
+ * forward() returns for that utterance alone (B = 1, T = frames[b]) — every layer treats the rows past the utterance's
+ * end as the reference's zero padding (model.py:8-10, "SAME") and skips the tiles beyond it — and the rest of its
+ * [hop*T] slot is zero.  The reference has no batching at all (mel2wave.py:20-41 runs one utterance); this is the
+ * throughput form of running it once per sentence.
+ *   frames_dev : [B] int32, device memory
+ */
+int vtts_hifigan_forward_ragged(vtts_hifigan* h, const float* mel_dev, const int32_t* frames_dev, int B, int T, float* wav_dev,
+                                void* workspace, size_t workspace_bytes, vtts_stream stream);
+
+/*
  * forward() that also copies one intermediate out, for parity tests.  `tap` names follow the
  * oracle: "conv_pre", "ups_<i>", "mrf_<i>" (each [B, C, L] fp32, channel-major) and
  * "pre_tanh" ([B, hop*T]).  tap_dev must hold vtts_hifigan_tap_elems() floats.

@@ -102,6 +102,14 @@ int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lma
  *                 JAX's threefry PRNG through Haiku's per-scan-step key splitting; that stream is the caller's business.
  *   mel_dev       [B, Fmax, mel_dim] fp32 log-mel (decoder output + postnet residual); rows past nframes are zero
  */
+/*
+ * Draws keep masks for forward() on the device: keep_dev [B, Fmax, 2, prenet_dim] bytes, P(keep) = 1/2 (hk.dropout(key,
+ * 0.5, x), model.py:97,:99), from seeds_dev [B] (one 64-bit seed per sentence, so a sentence's masks do not depend on
+ * the batch it is in) with Threefry-2x32-20: key = seed, counter = (2 * frame + layer, 64-column block), output bit j =
+ * column 64 * block + j.  The cipher is the one jax.random uses; the STREAM is this library's own — the reference's
+ * masks come from Haiku's per-scan-step splitting of the checkpoint's rng (text2mel.py:72-73), which is not restated.
+ */
+int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint64_t* seeds_dev, int B, int Fmax, uint8_t* keep_dev, void* stream);
 int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
                               const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
                               const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream);

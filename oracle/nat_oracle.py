@@ -223,3 +223,41 @@ def acoustic_inference(
             )
             y = np.tanh(y)
     return out + y
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Keep masks as the HIP library draws them (include/vtts_nat.h: vtts_nat_acoustic_keep_masks): Threefry-2x32 with 20 rounds
+# (Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11 — Random123's threefry2x32_R(20, ...),
+# the block cipher jax.random uses).  Pinned by Random123's known-answer vectors (tests/test_nat_cpu.py).  NOT Haiku's
+# key-splitting schedule: only the cipher is shared with the reference.
+# ---------------------------------------------------------------------------------------------------------------------
+_TF_ROT = (13, 15, 26, 6, 17, 29, 16, 24)
+
+
+def threefry2x32_20(k0, k1, x0, x1):
+    """Vectorised over numpy uint32 arrays (or scalars)."""
+    k0, k1, x0, x1 = (np.asarray(v, dtype=np.uint32) for v in (k0, k1, x0, x1))
+    ks = (k0, k1, np.uint32(0x1BD11BDA) ^ k0 ^ k1)
+    with np.errstate(over="ignore"):
+        x0 = x0 + ks[0]
+        x1 = x1 + ks[1]
+        for g in range(5):
+            for r in range(4):
+                rot = _TF_ROT[(g & 1) * 4 + r]
+                x0 = x0 + x1
+                x1 = (x1 << np.uint32(rot)) | (x1 >> np.uint32(32 - rot))
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(g + 1) % 3]
+            x1 = x1 + ks[(g + 2) % 3] + np.uint32(g + 1)
+    return x0, x1
+
+
+def threefry_keep_masks(seed: int, n_frames: int, prenet_dim: int = 256) -> np.ndarray:
+    """``[n_frames, 2, prenet_dim]`` boolean keep masks of one sentence: key = seed, counter = (2 * frame + layer,
+    64-column block), bit j of (x0 | x1 << 32) = column 64 * block + j."""
+    nblk = (prenet_dim + 63) // 64
+    ctr0 = np.repeat(np.arange(2 * n_frames, dtype=np.uint32), nblk)
+    ctr1 = np.tile(np.arange(nblk, dtype=np.uint32), 2 * n_frames)
+    x0, x1 = threefry2x32_20(np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF), ctr0, ctr1)
+    bits = np.concatenate([(x0[:, None] >> np.arange(32, dtype=np.uint32)) & 1, (x1[:, None] >> np.arange(32, dtype=np.uint32)) & 1], axis=1)
+    return bits.reshape(n_frames, 2, nblk * 64)[:, :, :prenet_dim].astype(bool)

@@ -215,3 +215,30 @@ def test_bf16_rejects_unsupported_architecture(dev):
 
     with pytest.raises(_lib.VttsError):
         Generator(TINY, device=dev, dtype="bf16")
+
+
+@pytest.mark.parametrize("fuse", [2, 1, 0])
+def test_ragged_batch_equals_each_utterance_alone(fuse):
+    """vtts_hifigan_forward_ragged: utterances of different lengths in one batch; every utterance's samples are bit for
+    bit those of running it alone with T = its own length (per-utterance zero padding at every layer), the rest of its
+    slot is zero.  Lengths straddle tile boundaries of several stages (1 frame ... several tiles)."""
+    from viettts_amd.hifigan.generator import Generator
+
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    gen.set_option("fuse", fuse)
+    try:
+        frames = [1, 2, 5, 13, 31, 32, 33, 47, 64, 3]
+        T = max(frames)
+        g = torch.Generator().manual_seed(99)
+        mel = torch.clamp(-5 + 2 * torch.randn(len(frames), T, 80, generator=g), -11.5129, 2.0)
+        for b, n in enumerate(frames):
+            mel[b, n:] = 123.0  # whatever sits past the end must not matter
+        mel = mel.to("cuda:0")
+        got = gen.forward_ragged(mel, frames).cpu().numpy()
+        for b, n in enumerate(frames):
+            alone = gen(mel[b : b + 1, :n].contiguous()).cpu().numpy()[0]
+            assert np.array_equal(got[b, : 256 * n], alone), (b, n)
+            assert not got[b, 256 * n :].any()
+    finally:
+        gen.close()

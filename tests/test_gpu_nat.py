@@ -195,3 +195,48 @@ def test_pipeline_sharded_equals_unsharded(model, acoustic):
         assert sum(w.shape[0] for w in whole.values()) > 0
     finally:
         gen.close()
+
+
+def test_device_keep_masks_equal_the_threefry_restatement(acoustic):
+    """Masks drawn by the library on the GPU == oracle/nat_oracle.py::threefry_keep_masks (pinned by Random123's
+    known answers on the CPU side), and a sentence's masks do not depend on the batch it is in."""
+    am, _, _ = acoustic
+    seeds = [0, 1, 2**40 + 17, 2**62 + 5]
+    got = am.device_keep_masks(seeds, 37).cpu().numpy()
+    assert got.shape == (4, 37, 2, 256) and got.dtype == np.uint8
+    for i, sd in enumerate(seeds):
+        assert np.array_equal(got[i].astype(bool), no.threefry_keep_masks(sd, 37, 256)), sd
+    alone = am.device_keep_masks([seeds[2]], 37).cpu().numpy()[0]
+    assert np.array_equal(alone, got[2])
+
+
+def test_acoustic_with_device_masks_matches_oracle(acoustic):
+    """The product path: dropout seeds in, masks drawn on the GPU; the oracle gets the same masks from the restatement."""
+    am, P, S = acoustic
+    rng = np.random.default_rng(77)
+    sents = [list(rng.integers(0, 100, size=L)) for L in (7, 19)]
+    durs = [np.abs(rng.normal(2.0, 0.7, size=len(s))).astype(np.float32) + 0.3 for s in sents]
+    nfr = [int(np.sum(d, dtype=np.float32)) for d in durs]
+    seeds = [901, 902]
+    got = am(sents, durs, nfr, dropout_seeds=seeds)
+    for s, d, n, sd, g in zip(sents, durs, nfr, seeds, got):
+        masks = no.threefry_keep_masks(sd, n, 256)
+        ref = no.acoustic_inference(P, S, np.array(s), d, n, prenet_masks=lambda f, m=masks: (m[f, 0], m[f, 1]))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(g - ref).max() / scale < 5e-4
+
+
+def test_acoustic_wide_batch_rows_equal_rows_alone(acoustic):
+    """More than 32 sentences take the two-tiles-per-wave decoder step; every row still equals the row run alone (and
+    the oracle), finished sentences idle while longer ones keep decoding."""
+    m, P, S = acoustic
+    cases = [_case(500 + i, 2 + (i * 7) % 13) for i in range(41)]
+    seeds = [3000 + i for i in range(41)]
+    got = m([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], dropout_seeds=seeds)
+    for i in (0, 17, 33, 40):
+        tok, dur, nf = cases[i]
+        assert np.array_equal(m([tok], [dur], [nf], dropout_seeds=[seeds[i]])[0], got[i]), i
+    tok, dur, nf = cases[40]
+    masks = no.threefry_keep_masks(seeds[40], nf, 256)
+    ref = no.acoustic_inference(P, S, np.array(tok), dur, nf, prenet_masks=lambda f: (masks[f, 0], masks[f, 1]))
+    assert np.abs(got[40] - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())

@@ -117,8 +117,11 @@ def test_acoustic_param_table_matches_synthetic_checkpoint(lib):
     nb = C.c_size_t(0)
     assert lib.vtts_nat_acoustic_workspace_bytes(h, 1, 10, 0, C.byref(nb)) == -1
     lib.vtts_nat_acoustic_destroy(h)
-    bad = _lib.NatAcousticCfg(256, 256, 256, 256, 80, 512)  # decoder_dim != 512
+    bad = _lib.NatAcousticCfg(256, 256, 500, 256, 80, 512)  # decoder_dim not a multiple of 32 (matrix-core k-steps)
     assert lib.vtts_nat_acoustic_create(C.byref(bad), 0, C.byref(h)) == -1
+    other = _lib.NatAcousticCfg(256, 128, 256, 64, 80, 256)  # other widths are fine
+    assert lib.vtts_nat_acoustic_create(C.byref(other), 0, C.byref(h)) == 0
+    lib.vtts_nat_acoustic_destroy(h)
 
 
 def test_acoustic_oracle_properties():
@@ -135,3 +138,21 @@ def test_acoustic_oracle_properties():
     x = np.eye(6, dtype=np.float64)
     w = no.gaussian_upsample(x, dur.astype(np.float64), nf)
     assert np.allclose(w.sum(axis=1), 1.0) and w.min() >= 0
+
+
+def test_threefry_known_answers():
+    """Random123's kat_vectors for threefry2x32 with 20 rounds (the same three jax's own test suite uses) pin the cipher
+    behind the device-drawn dropout masks."""
+    from oracle.nat_oracle import threefry2x32_20, threefry_keep_masks
+
+    for key, ctr, want in (
+        ((0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6B200159, 0x99BA4EFE)),
+        ((0xFFFFFFFF, 0xFFFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (0x1CB996FC, 0xBB002BE7)),
+        ((0x13198A2E, 0x03707344), (0x243F6A88, 0x85A308D3), (0xC4923A9C, 0x483DF7A0)),
+    ):
+        x0, x1 = threefry2x32_20(key[0], key[1], ctr[0], ctr[1])
+        assert (int(x0), int(x1)) == want
+    m = threefry_keep_masks(12345, 40, 256)
+    assert m.shape == (40, 2, 256) and 0.47 < m.mean() < 0.53
+    assert not np.array_equal(m, threefry_keep_masks(12346, 40, 256))
+    assert np.array_equal(m[:10], threefry_keep_masks(12345, 10, 256))  # a frame's mask does not depend on the sentence's length

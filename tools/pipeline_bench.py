@@ -2,18 +2,19 @@
 synthetic checkpoints) through duration model -> frame rules -> acoustic model -> HiFi-GAN (bf16).  Prints one JSON line
 with per-stage wall times (device-synchronised) — a development measurement; the judged line is bench.py's."""
 import json
+import os
 import sys
 import time
 
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from viettts_amd.hifigan.config import V1  # noqa: E402
 from viettts_amd.hifigan.generator import Generator  # noqa: E402
 from viettts_amd.hifigan.synth import synthetic_params  # noqa: E402
 from viettts_amd.nat import text2mel as t2m  # noqa: E402
-from viettts_amd.nat.acoustic import AcousticModel, bernoulli_keep_masks  # noqa: E402
+from viettts_amd.nat.acoustic import AcousticModel  # noqa: E402
 from viettts_amd.nat.config import FLAGS  # noqa: E402
 from viettts_amd.nat.duration import DurationModel  # noqa: E402
 from viettts_amd.nat.synth import synthetic_acoustic_checkpoint, synthetic_duration_checkpoint  # noqa: E402
@@ -51,20 +52,23 @@ def main():
             d = t2m.apply_duration_rules(t, d[None, :], 0.05)
             frames.append(t2m.durations_to_frames(d)[0])
             nfr.append(max(1, t2m.n_frames_from_durations(d)))
-        keep = [bernoulli_keep_masks(k, 7 + i) for i, k in enumerate(nfr)]
         t2 = time.perf_counter()
-        mels = am(sents, frames, nfr, keep_masks=keep)
+        mels = am(sents, frames, nfr, dropout_seeds=[7 + i for i in range(len(sents))])
         sync(); t3 = time.perf_counter()
-        by_len = {}
-        for k, m in enumerate(mels):
-            by_len.setdefault(m.shape[0], []).append(k)
-        nsamp = 0
-        for T, ks in by_len.items():
-            w = gen(torch.from_numpy(np.stack([mels[k] for k in ks])).to("cuda:0"))
-            nsamp += w.numel()
+        order = sorted(range(len(mels)), key=lambda k: mels[k].shape[0])
+        nsamp, nbatches = 0, 0
+        for i0 in range(0, len(order), 64):
+            ks = order[i0 : i0 + 64]
+            fr = [mels[k].shape[0] for k in ks]
+            batch = np.zeros((len(ks), max(fr), 80), dtype=np.float32)
+            for r, k in enumerate(ks):
+                batch[r, : fr[r]] = mels[k]
+            w = gen.forward_ragged(torch.from_numpy(batch).to("cuda:0"), fr)
+            nsamp += 256 * sum(fr)
+            nbatches += 1
         sync(); t4 = time.perf_counter()
         res = {"sentences": n, "tokens": int(sum(map(len, sents))), "frames": int(sum(nfr)), "frames_max": int(max(nfr)), "samples": int(nsamp),
-               "length_buckets": len(by_len), "duration_s": t1 - t0, "host_rules_masks_s": t2 - t1, "acoustic_s": t3 - t2, "generator_s": t4 - t3,
+               "generator_batches": nbatches, "duration_s": t1 - t0, "host_rules_s": t2 - t1, "acoustic_s": t3 - t2, "generator_s": t4 - t3,
                "total_s": t4 - t0, "samples_per_s": nsamp / (t4 - t0)}
     print(json.dumps(res))
 

@@ -42,6 +42,7 @@ EXPORTS = (
     "vtts_hifigan_bind_packed",
     "vtts_hifigan_workspace_bytes",
     "vtts_hifigan_forward",
+    "vtts_hifigan_forward_ragged",
     "vtts_hifigan_tap_elems",
     "vtts_hifigan_forward_tap",
     "vtts_hifigan_run_module",
@@ -74,6 +75,7 @@ NAT_EXPORTS = (
     "vtts_nat_acoustic_pack",
     "vtts_nat_acoustic_bind_packed",
     "vtts_nat_acoustic_workspace_bytes",
+    "vtts_nat_acoustic_keep_masks",
     "vtts_nat_acoustic_forward",
 )
 
@@ -173,6 +175,7 @@ def load(path=None) -> C.CDLL:
         "vtts_hifigan_bind_packed": (C.c_int, [vp, vp, sz]),
         "vtts_hifigan_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(sz)]),
         "vtts_hifigan_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, sz, vp]),
+        "vtts_hifigan_forward_ragged": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, sz, vp]),
         "vtts_hifigan_tap_elems": (C.c_int, [vp, cp, C.c_int, C.c_int, C.POINTER(sz)]),
         "vtts_hifigan_forward_tap": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, cp, vp]),
         "vtts_hifigan_run_module": (C.c_int, [vp, cp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
@@ -200,6 +203,7 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_acoustic_pack": (C.c_int, [vp, vp, sz, vp]),
         "vtts_nat_acoustic_bind_packed": (C.c_int, [vp, vp, sz]),
         "vtts_nat_acoustic_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(sz)]),
+        "vtts_nat_acoustic_keep_masks": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():

@@ -98,6 +98,9 @@ struct vtts_hifigan {
     int64_t opt_kernels = 0;         // 0 auto, 1 generic only
     int64_t opt_microbatch = 0;      // 0 auto
     int64_t opt_profile = 0;
+    int cur_b0 = 0;                 // first utterance of the micro-batch being launched
+    const int* cur_lens = nullptr;  // ragged forward in flight: valid mel frames per utterance (device) ...
+    int cur_T = 0;                  // ... of the T allocated
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
     int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
@@ -379,6 +382,12 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
 
 
 // ---- bf16 path -------------------------------------------------------------------------------------
+// ragged batches (vtts_hifigan_forward_ragged): every layer learns each utterance's valid rows = frames * (rows per frame)
+void set_ragged(const vtts_hifigan* h, BConvArgs& a, int L) {
+    a.lens = h->cur_lens ? h->cur_lens + h->cur_b0 : nullptr;
+    a.len_mul = h->cur_lens ? L / h->cur_T : 1;
+}
+
 int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, int cin_real, int B, int L, float slope_in,
                    float slope_out, const void* res, void* y, int acc_add, float div, hipStream_t s) {
     BConvArgs a;
@@ -390,6 +399,7 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
     a.y = y;
     a.B = B;
     a.L = L;
+    set_ragged(h, a, L);
     a.x_pitch = x_pitch;
     a.cin_real = cin_real;
     a.dil = (l.kind == KIND_CONVT) ? 1 : l.dil;
@@ -429,6 +439,7 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     a.y = y;
     a.B = B;
     a.L = L;
+    set_ragged(h, a, L);
     a.x_pitch = c1.cin;
     a.cin_real = c1.cin;
     a.dil = c1.dil;
@@ -467,6 +478,7 @@ int run_resblock_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, in
     a.y = y;
     a.B = B;
     a.L = L;
+    set_ragged(h, a, L);
     a.x_pitch = rb[0].cin;
     a.cin_real = rb[0].cin;
     a.dils[0] = rb[0].dil;
@@ -582,6 +594,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
         char* bufC = wsb + 2 * per;
         char* bufS = wsb + 3 * per;
         const int nb = std::min(mb, B - b0);
+        h->cur_b0 = b0;
         int rc;
         {
             const Layer& l = h->layers[h->idx_pre];
@@ -658,6 +671,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             a.bias = reinterpret_cast<const float*>(h->blob + l.off_b);
             a.B = nb;
             a.L = (int)L;
+            set_ragged(h, a, (int)L);
             float* pre = (tap.name && !strcmp(tap.name, "pre_tanh")) ? tap.out + (size_t)b0 * wav_len : nullptr;
             hipError_t e = launch_conv_post_bf16(a, wav + (size_t)b0 * wav_len, pre, s);
             if (e != hipSuccess) return fail(VTTS_ERR_HIP, "conv_post launch failed: %s", hipGetErrorString(e));
@@ -972,6 +986,21 @@ VTTS_API int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, 
                                   size_t workspace_bytes, vtts_stream stream) {
     if (!h || !mel_dev || !wav_dev) return fail(VTTS_ERR_INVALID, "null argument");
     return forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream), Taps{});
+}
+
+VTTS_API int vtts_hifigan_forward_ragged(vtts_hifigan* h, const float* mel_dev, const int32_t* frames_dev, int B, int T, float* wav_dev,
+                                         void* workspace, size_t workspace_bytes, vtts_stream stream) {
+    if (!h || !mel_dev || !frames_dev || !wav_dev) return fail(VTTS_ERR_INVALID, "null argument");
+    if (h->dtype != VTTS_BF16) return fail(VTTS_ERR_INVALID, "ragged batches run on the bf16 engine (the fp32 engine takes equal-length batches)");
+    if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive (got B=%d, T=%d)", B, T);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(wav_dev, 0, (size_t)B * h->hop * T * sizeof(float), s));  // samples past an utterance's end
+    h->cur_lens = frames_dev;
+    h->cur_T = T;
+    const int rc = forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, s, Taps{});
+    h->cur_lens = nullptr;
+    h->cur_T = 0;
+    return rc;
 }
 
 VTTS_API int vtts_hifigan_tap_elems(const vtts_hifigan* h, const char* tap, int B, int T, size_t* elems) {

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
     const int t0 = blockIdx.x * NT;
     const int mtile = blockIdx.y;
     const int b = blockIdx.z;
-    const int L = a.L;
+    const int Lp = a.L;                                      // rows allocated per utterance
+    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    if (t0 >= L) return;  // a tile past this utterance's end
 
     const uint4* __restrict__ wsl = reinterpret_cast<const uint4*>(a.wp) + (size_t)mtile * NSTOT * T::SLAB_UNITS;
 
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
                 const int ch = cc * XC + c * 8;
                 if constexpr (T::IN_F32) {
                     if (ch < a.cin_real) {
-                        const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ((size_t)b * L + t) * a.x_pitch + ch);
+                        const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(a.x) + ((size_t)b * Lp + t) * a.x_pitch + ch);
                         const float4 f0 = src[0], f1 = src[1];
                         v[i] = make_uint4(pack_bf16x2(f0.x, f0.y), pack_bf16x2(f0.z, f0.w), pack_bf16x2(f1.x, f1.y), pack_bf16x2(f1.z, f1.w));
                     }
                 } else {
-                    v[i] = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(a.x) + ((size_t)b * L + t) * a.x_pitch + ch);
+                    v[i] = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(a.x) + ((size_t)b * Lp + t) * a.x_pitch + ch);
                 }
             }
         }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         const float4 p0 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8);
         const float4 p1 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8 + 4);
         float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
-        const size_t g = ((size_t)b * L + t) * COUTP + mtile * MT + c8 * 8;
+        const size_t g = ((size_t)b * Lp + t) * COUTP + mtile * MT + c8 * 8;
         if (res) {  // ResBlock residual  x = xt + x  (model.py:50)
             const uint4 r = *reinterpret_cast<const uint4*>(res + g);
             v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
@@ -420,10 +422,12 @@ __global__ __launch_bounds__(256) void conv_post_bf16_k(BConvArgs a, float* __re
     __shared__ float ws[KS * C];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const int L = a.L;
+    const int Lp = a.L;                                      // rows allocated per utterance
+    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
     const long t0 = (long)blockIdx.x * NT;
+    if (t0 >= L) return;  // samples past this utterance's end: zero by the caller's memset
     for (int i = tid; i < KS * C; i += 256) ws[i] = a.wf[i];  // Haiku [K][Cin][1] fp32
-    const unsigned short* __restrict__ xb = static_cast<const unsigned short*>(a.x) + (size_t)b * L * C;
+    const unsigned short* __restrict__ xb = static_cast<const unsigned short*>(a.x) + (size_t)b * Lp * C;
     for (int u = tid; u < ROWS * SPR; u += 256) {
         const int row = u / SPR, c = u % SPR;
         const long t = t0 - 3 + row;
@@ -449,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_post_bf16_k(BConvArgs a, float* __re
         }
     }
     const float p = acc + a.bias[0];
-    const size_t idx = (size_t)b * L + t;
+    const size_t idx = (size_t)b * Lp + t;
     if (pre_act) pre_act[idx] = p;
     wav[idx] = tanhf(p);
 }

@@ -78,11 +78,13 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int lh = lane >> 5;
     const int t0 = blockIdx.x * NT2;         // first output time step of this workgroup
     const int b = blockIdx.z;
-    const int L = a.L;
+    const int Lp = a.L;                                      // rows allocated per utterance
+    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    if (t0 >= L) return;                                     // a tile past this utterance's end: nothing reads its rows
     const int dil = a.dil;
     const int h1 = H2 * dil;                 // c1's symmetric pad (model.py:8-10)
     const int rowsx = N1 + 2 * h1;           // X rows: times t0 - H2 - h1 ... t0 - H2 - h1 + rowsx - 1
-    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * L * C;
+    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * Lp * C;
     [[maybe_unused]] const int wg_lin = blockIdx.z * gridDim.x + blockIdx.x;
     VTTS_TL_ID(a, wg_lin);
     VTTS_TL(a, wg_lin, 0);
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     {
         const float s_out = a.slope_out;
         const float dv = a.div;
-        unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * L * C;
+        unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * Lp * C;
         // rows of a [B][L][C] tensor in the swapped accumulator layout: all requests first, one wait
         auto add_rows = [&](const unsigned short* __restrict__ src) {
             uint4 rv[MR][2][NR];

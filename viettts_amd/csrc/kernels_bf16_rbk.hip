@@ -72,14 +72,16 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int l31 = lane & 31;
     const int lh = lane >> 5;
     const int b = blockIdx.z;
-    const int L = a.L;
+    const int Lp = a.L;                                      // rows allocated per utterance
+    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
     const int d0 = a.dils[0], d1 = a.dils[1], d2 = a.dils[2];
     const int M = H * (d0 + d1 + d2) + 3 * H;  // invalid margin per side after the three pairs
     const int NT = W - 2 * M;                  // outputs per workgroup
     const int t0 = blockIdx.x * NT;            // first output time step
+    if (t0 >= L) return;                       // a tile past this utterance's end
     const int tw = t0 - M;                     // time of window row 0
-    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * L * C;
-    unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * L * C;
+    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * Lp * C;
+    unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * Lp * C;
 
     auto swap_pair = [](unsigned& pd, unsigned& qd) {
         auto r = __builtin_amdgcn_permlane32_swap(pd, qd, false, false);

@@ -26,6 +26,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -75,6 +76,12 @@ struct NatModel {
     std::vector<Arr> arrs;
     std::vector<std::pair<std::string, int>> bns;  // (BatchNorm module tail, channels)
     std::vector<size_t> bn_off;
+    struct Extra {  // a kernel-private re-layout of checkpoint arrays, built at pack() time behind the plain arrays
+        std::string key;
+        size_t bytes = 0, off = 0;
+        std::function<void(const NatModel&, float*)> fill;
+    };
+    std::vector<Extra> extras;
     size_t blob_bytes = 0;
     char* blob = nullptr;
 
@@ -106,6 +113,18 @@ struct NatModel {
             add(te + l, "b", {4 * D});
         }
     }
+    void add_extra(const std::string& key, size_t bytes, std::function<void(const NatModel&, float*)> fill) {
+        Extra e;
+        e.key = key;
+        e.bytes = bytes;
+        e.fill = std::move(fill);
+        extras.push_back(std::move(e));
+    }
+    const float* extra(const std::string& key) const {
+        for (auto& e : extras)
+            if (e.key == key) return reinterpret_cast<const float*>(blob + e.off);
+        return nullptr;
+    }
     void layout() {
         size_t off = 0;
         for (auto& a : arrs) {
@@ -115,6 +134,10 @@ struct NatModel {
         for (auto& b : bns) {
             bn_off.push_back(off);
             off = align_up(off + (size_t)b.second * sizeof(float), 256);
+        }
+        for (auto& e : extras) {
+            e.off = off;
+            off = align_up(off + e.bytes, 256);
         }
         blob_bytes = off;
     }
@@ -166,6 +189,7 @@ struct NatModel {
             float* iv = reinterpret_cast<float*>(img.data() + bn_off[i]);
             for (int c = 0; c < bns[i].second; ++c) iv[c] = sc.host[c] / std::sqrt(var.host[c] + 1e-5f);  // hk.BatchNorm eps
         }
+        for (auto& e : extras) e.fill(*this, reinterpret_cast<float*>(img.data() + e.off));
         HIP_TRYN(hipMemcpyAsync(dev_blob, img.data(), blob_bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
         HIP_TRYN(hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // img dies at return
         blob = static_cast<char*>(dev_blob);
@@ -253,6 +277,123 @@ __global__ __launch_bounds__(256) void nat_conv_bn_act_k(const float* __restrict
             }
         }
     }
+}
+
+// Postnet convolutions (model.py:113-121) on the fp32 matrix cores: y = act(batchnorm_eval(conv1d_same(x))) [+ res],
+// channels-last fp32 rows, same zero-beyond-the-length semantics as nat_conv_bn_act_k.  GEMM view: M = cout (A = weights,
+// host-packed [mblk][32-channel step][tap][lane][16]: element i of lane = W[tap][32*cs + 16*(lane/32) + i][32*mblk + lane%32]),
+// N = frame, k = (32-channel step, tap, channel): for one step a lane reads 64 contiguous bytes of its frame's row, the
+// other half-wave the next 64, so every 128-byte line fetched is used in full and the (64 + K - 1)-row window of a step
+// stays in L1 across the taps.  A wave owns MR x 2 accumulator blocks (32 couts x 32 frames each); no LDS, no barrier:
+// latency is covered by several workgroups per CU.
+template <int K, int MR>
+__global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__ x, const int* __restrict__ lengths, const float4* __restrict__ wpk,
+                                                       const float* __restrict__ bias, const float* __restrict__ inv, const float* __restrict__ mean,
+                                                       const float* __restrict__ offset, const float* __restrict__ res, float* __restrict__ y, int Lmax,
+                                                       int Cin, int Cout, int act) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int NR = 2, PL = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, t0 = blockIdx.x * 64;
+    const int len = lengths[b];
+    const int MB = (Cout + 31) / 32, NCS = (Cin + 31) / 32;
+    const int mb0 = (blockIdx.y * 4 + wave) * MR;
+    if (t0 >= len || mb0 >= MB) return;  // rows at or past the length: zero by the caller's memset (last layer) or masked by the reader
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 32 * (mb0 + mr) + 8 * rq + 4 * lh + i;
+                const float bv = (mb0 + mr < MB && co < Cout) ? bias[co] : 0.0f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) acc[mr][nr][4 * rq + i] = bv;
+            }
+    const float* __restrict__ xb = x + (size_t)b * Lmax * Cin;
+    for (int cs = 0; cs < NCS; ++cs) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float4 av[MR][4], bv[NR][4];
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;  // a wave's spare block re-reads the last one; never stored
+                const float4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 64 + lane) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[mr][q] = ap[q];
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = t0 + nr * 32 + l31 + j - PL;
+                const int tc = t < 0 ? 0 : (t >= len ? len - 1 : t);  // unconditional loads from clamped addresses, masked afterwards
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cs * 32 + 16 * lh + 4 * q;
+                    const int cc = c + 4 <= Cin ? c : Cin - 4;
+                    float4 v = *reinterpret_cast<const float4*>(xb + (size_t)tc * Cin + cc);
+                    if (t != tc || c != cc) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    bv[nr][q] = v;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].x, bv[nr][q].x, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].y, bv[nr][q].y, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].z, bv[nr][q].z, acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].w, bv[nr][q].w, acc[mr][nr], 0, 0, 0);
+            }
+        }
+    }
+    const bool bn = inv != nullptr;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int co = 32 * (mb0 + mr) + 8 * rq + 4 * lh;
+            if (mb0 + mr >= MB || co >= Cout) continue;  // Cout is a multiple of 4: a lane's 4 channels are in or out together
+            float iv[4] = {1.f, 1.f, 1.f, 1.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    iv[i] = inv[co + i];
+                    mv[i] = mean[co + i];
+                    ov[i] = offset[co + i];
+                }
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = t0 + nr * 32 + l31;
+                if (t >= Lmax) continue;
+                const size_t o = ((size_t)b * Lmax + t) * Cout + co;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[mr][nr][4 * rq + i];
+                    if (bn) v[i] = (v[i] - mv[i]) * iv[i] + ov[i];
+                    if (act == NAT_ACT_RELU) v[i] = fmaxf(v[i], 0.0f);
+                    else if (act == NAT_ACT_TANH) v[i] = tanhf(v[i]);
+                }
+                if (res) {
+                    const float4 r = *reinterpret_cast<const float4*>(res + o);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                if (t >= len) v[0] = v[1] = v[2] = v[3] = 0.0f;
+                *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
 }
 
 // hk.LSTM over one sentence in one direction (model.py:39-45).  grid = (B, 2); blockDim = 4*D (one thread per gate
@@ -377,124 +518,256 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
     }
 }
 
-// AcousticModel.inference's scan body (model.py:134-141), one persistent 1024-thread workgroup per sentence:
+// AcousticModel.inference's scan body (model.py:134-141) for ALL sentences of the batch at once, one launch per layer per
+// frame (the recurrence is sequential in frames; sentences are independent):
 //   p = dropout(relu(dropout(relu(prev @ f1)) @ f2))           prenet, no bias, rate 0.5, ALWAYS on (model.py:95-100);
 //                                                               keep[b][f][0|1][PN] bytes (1 = keep, value * 2), nullptr = none
 //   x = [cond_f ; p];  h1 = LSTM1([x ; h1]);  h2 = LSTM2([[h1 ; x] ; h2])      hk.deep_rnn_with_skip_connections
 //   mel_f = [h1 ; h2] @ wp + bp;  prev = mel_f
-// Gate columns: thread g owns columns g and g + 1024 of each [in x 4H] matrix (coalesced across threads).
-__global__ __launch_bounds__(1024) void nat_decoder_k(const float* __restrict__ cond, const int* __restrict__ nframes, const float* __restrict__ f1,
-                                                      const float* __restrict__ f2, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ wp,
-                                                      const float* __restrict__ bp, const unsigned char* __restrict__ keep,
-                                                      float* __restrict__ mel, int Fmax, int E, int PN, int H, int MEL) {
-    extern __shared__ float sd[];
-    float* xin = sd;                 // [E + PN]
-    float* h1 = xin + E + PN;        // [H]
-    float* h2 = h1 + H;              // [H]
-    float* gates = h2 + H;           // [4H]
-    float* prev = gates + 4 * H;     // [MEL]
-    float* p1 = prev + MEL;          // [PN]
-    float* part = p1 + PN;           // [8 * MEL]
-    const int b = blockIdx.x, g = threadIdx.x;
-    const int nf = nframes[b];
-    const int X = E + PN, G4 = 4 * H;
-    float c1 = 0.0f, c2 = 0.0f;
-    if (g < H) {
-        h1[g] = 0.0f;
-        h2[g] = 0.0f;
+// Decoder state in HBM, k-major with the sentences contiguous (Bp = B rounded up to 32 columns), ping-pong by frame parity:
+//   Z[parity][row][Bp], rows [ h1 (H) | cond_f (E) | p (PN) | h2 (H) ]:  LSTM1 reads rows [H, H+E+PN) of the current
+//   parity then h1 of the previous one; LSTM2 reads rows [0, H+E+PN) of the current parity then h2 of the previous one —
+//   exactly the row order of the two Haiku weight matrices.  Cell states c1, c2 as [H][Bp].
+//
+// nat_dec_lstm_k: gates[32 sentences x (8 units x 4 gates)] per wave on the fp32 matrix cores (v_mfma_f32_32x32x2_f32:
+// M = the slice's 32 gate columns ordered 4*unit + gate, N = 32 sentences, K = 2 per instruction).  With that row order a
+// lane's 16 accumulators are the i, g, f, o pre-activations of 4 (unit, sentence) pairs: the LSTM cell update
+// (hk.LSTM: gates i, g, f, o; forget bias +1) happens in registers, no exchange.  Weights host-packed per slice so that one
+// 16-byte load per lane feeds 4 MFMAs ([slice][K/8][lane][4]: element i = W[8*kb + 2*i + lane/32][col(lane%32)]);
+// activations straight from Z (128-byte rows, L2-resident); both PD iterations (8 k each) ahead in registers.
+// Every output element depends on its own sentence's column only: rows are bit-identical alone or batched.
+constexpr int NAT_DEC_PD = 4;   // iterations (8 k each) a wave keeps in flight
+
+// NT = 32-sentence tiles per wave (one weight fragment feeds NT MFMAs: L2 traffic for the weights / NT), KW = waves per
+// workgroup, each with a contiguous share of K; their partial sums meet in LDS in a fixed tree order.
+template <int NT, int KW>
+__global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restrict__ inA, int KA, const float* __restrict__ inB, int KB,
+                                                          const float4* __restrict__ wpk, const float* __restrict__ bias, float* __restrict__ cst,
+                                                          float* __restrict__ hout, const int* __restrict__ nframes, int f, int B, int Bp, int H) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    static_assert(KW == 1 || KW == 2 || KW == 4 || KW == 8, "tree reduction");
+    __shared__ float red[KW > 1 ? KW / 2 : 1][NT][16][64];
+    const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.x, b0 = blockIdx.y * 32 * NT;
+    bool live[NT];
+    bool any = false;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int b = b0 + 32 * nt + l31;
+        live[nt] = b < B && f < nframes[b < B ? b : B - 1];
+        any = any || live[nt];
     }
-    if (g < MEL) prev[g] = 0.0f;
-    const float b1a = b1[g], b1b = b1[g + 1024], b2a = b2[g], b2b = b2[g + 1024];
+    if (__ballot(any) == 0ull) return;  // every sentence of these tiles has all its frames (same for all waves)
+    const int NIT = (KA + KB) / 8, NWMAX = (NIT + KW - 1) / KW, it_lo = kw * NWMAX;
+    const int NW = it_lo >= NIT ? 0 : (NIT - it_lo < NWMAX ? NIT - it_lo : NWMAX);  // this wave's iterations [it_lo, it_lo + NW)
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float bv = kw == 0 ? bias[i * H + 8 * slice + 2 * rq + lh] : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt][0][4 * rq + i] = bv;
+                acc[nt][1][4 * rq + i] = 0.0f;
+            }
+        }
+    float4 wv[NAT_DEC_PD];
+    float xv[NAT_DEC_PD][NT][4];
+    const float4* __restrict__ wsl = wpk + (size_t)slice * NIT * 64 + lane;
+    auto load_it = [&](int it, int slot) {
+        if (it >= NIT) it = NIT - 1;  // tail: an in-bounds re-read, never used
+        wv[slot] = wsl[(size_t)it * 64];
+        const int k0 = it * 8;
+        const float* __restrict__ xr = (k0 < KA ? inA + (size_t)k0 * Bp : inB + (size_t)(k0 - KA) * Bp) + (size_t)lh * Bp + b0 + l31;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[slot][nt][i] = xr[(size_t)(2 * i) * Bp + 32 * nt];
+    };
+#pragma unroll
+    for (int j = 0; j < NAT_DEC_PD; ++j) load_it(it_lo + j, j);
+#pragma nounroll
+    for (int it0 = 0; it0 < NW; it0 += NAT_DEC_PD) {
+#pragma unroll
+        for (int j = 0; j < NAT_DEC_PD; ++j) {
+            if (it0 + j >= NW) break;  // wave-uniform
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, xv[j][nt][0], acc[nt][0], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, xv[j][nt][1], acc[nt][1], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].z, xv[j][nt][2], acc[nt][0], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].w, xv[j][nt][3], acc[nt][1], 0, 0, 0);
+            const int nx = it0 + j + NAT_DEC_PD;
+            load_it(nx < NW ? it_lo + nx : NIT, j);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][0][r] += acc[nt][1][r];
+    // fixed-order tree over the K shares: waves [half, 2*half) hand their sums to waves [0, half)
+#pragma unroll
+    for (int half = KW / 2; half >= 1; half >>= 1) {
+        if (kw >= half && kw < 2 * half) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[kw - half][nt][r][lane] = acc[nt][0][r];
+        }
+        __syncthreads();
+        if (kw < half) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][0][r] += red[kw][nt][r][lane];
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (kw > 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!live[nt]) continue;
+        const int b = b0 + 32 * nt + l31;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int u = 8 * slice + 2 * rq + lh;
+            const float gi = acc[nt][0][4 * rq + 0], gg = acc[nt][0][4 * rq + 1], gf = acc[nt][0][4 * rq + 2], go = acc[nt][0][4 * rq + 3];
+            float c = cst[(size_t)u * Bp + b];
+            c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
+            cst[(size_t)u * Bp + b] = c;
+            hout[(size_t)u * Bp + b] = sigmoidf_(go) * tanhf(c);
+        }
+    }
+}
+
+// Keep masks for the prenet's dropout drawn on the device: Threefry-2x32 with 20 rounds (Salmon et al., SC'11 — the
+// block cipher jax.random is built on), key = the sentence's 64-bit seed, counter = (2 * frame + layer, 64-column block);
+// the 64 output bits are the keep flags of 64 consecutive prenet columns (P(keep) = 1/2 = 1 - rate, model.py:97,99).
+// This is a stream of our own: Haiku's per-scan-step key splitting is not restated (include/vtts_nat.h).
+__device__ __forceinline__ void threefry2x32_20(unsigned k0, unsigned k1, unsigned& x0, unsigned& x1) {
+    const unsigned ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
+    const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+    x0 += ks[0];
+    x1 += ks[1];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rot = R[(g & 1) * 4 + r];
+            x0 += x1;
+            x1 = (x1 << rot) | (x1 >> (32 - rot));
+            x1 ^= x0;
+        }
+        x0 += ks[(g + 1) % 3];
+        x1 += ks[(g + 2) % 3] + (unsigned)(g + 1);
+    }
+}
+__global__ void nat_keep_masks_k(const unsigned long long* __restrict__ seeds, unsigned char* __restrict__ keep, int B, int Fmax, int PN) {
+    const int nblk = (PN + 63) / 64;
+    const size_t n = (size_t)B * Fmax * 2 * nblk;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int blk = (int)(i % nblk);
+        const size_t fl = i / nblk;  // (b * Fmax + f) * 2 + layer
+        const int b = (int)(fl / (2 * (size_t)Fmax));
+        const unsigned ctr0 = (unsigned)(fl % (2 * (size_t)Fmax));
+        const unsigned long long sd = seeds[b];
+        unsigned x0 = ctr0, x1 = (unsigned)blk;
+        threefry2x32_20((unsigned)sd, (unsigned)(sd >> 32), x0, x1);
+        unsigned char* dst = keep + fl * PN + (size_t)blk * 64;
+        for (int j = 0; j < 64 && blk * 64 + j < PN; ++j) dst[j] = (unsigned char)(((j < 32 ? x0 >> j : x1 >> (j - 32)) & 1u));
+    }
+}
+
+// Frame 0's input: h1 = h2 = 0, c = 0 (memset), prenet(0) = 0 (no biases), cond_0 from the upsampler.
+__global__ void nat_dec_init_k(const float* __restrict__ cond, float* __restrict__ zcond, int B, int Bp, int Fmax, int E) {
+    const int b = blockIdx.x;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) zcond[(size_t)e * Bp + b] = cond[(size_t)b * Fmax * E + e];
+}
+
+// mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 and its cond row into the other parity's state.  One
+// 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
+// 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
+__global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext, const float* __restrict__ cond,
+                                                              const int* __restrict__ nframes, const float* __restrict__ f1, const float* __restrict__ f2,
+                                                              const float* __restrict__ wp, const float* __restrict__ bp,
+                                                              const unsigned char* __restrict__ keep, float* __restrict__ mel, int f, int B, int Bp,
+                                                              int Fmax, int E, int PN, int H, int MEL) {
+    extern __shared__ float4 sq[];
+    float4* hs = sq;              // [2H]   h1 ; h2 of the 4 sentences
+    float4* part = hs + 2 * H;    // [1024] partial sums of the product in flight
+    float4* prev = part + 1024;   // [MEL]
+    float4* p1 = prev + MEL;      // [PN]
+    const int g = threadIdx.x, b0 = blockIdx.x * 4;
+    int nf[4];
+    bool any = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        nf[s] = b0 + s < B ? nframes[b0 + s] : 0;
+        any = any || f < nf[s];
+    }
+    if (!any) return;
+    const int X = E + PN;
+    for (int k = g; k < 2 * H; k += 1024) hs[k] = *reinterpret_cast<const float4*>(zcur + (size_t)(k < H ? k : k + X) * Bp + b0);
     __syncthreads();
-    for (int f = 0; f < nf; ++f) {
-        const unsigned char* kp = keep ? keep + ((size_t)b * Fmax + f) * 2 * PN : nullptr;
-        if (g < PN) {
-            float a = 0.0f;
-            for (int k = 0; k < MEL; ++k) a = fmaf(prev[k], f1[(size_t)k * PN + g], a);
-            a = fmaxf(a, 0.0f);
-            if (kp) a = kp[g] ? a * 2.0f : 0.0f;
-            p1[g] = a;
-        } else if (g < PN + E) {
-            xin[g - PN] = cond[((size_t)b * Fmax + f) * E + (g - PN)];
+    // out[col] (4 sentences) = sum over chunk `ch` of rows [ch*per, (ch+1)*per) of src[row] * w[row][col]
+    auto partial = [&](const float4* __restrict__ src, const float* __restrict__ w, int rows, int width, int col, int ch, int per) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;
+#pragma unroll 8
+        for (int k = ch * per; k < k1; ++k) {
+            const float wv = w[(size_t)k * width + col];
+            const float4 x = src[k];
+            a.x = fmaf(x.x, wv, a.x); a.y = fmaf(x.y, wv, a.y); a.z = fmaf(x.z, wv, a.z); a.w = fmaf(x.w, wv, a.w);
         }
-        __syncthreads();
-        if (g < PN) {
-            float a = 0.0f;
-            for (int k = 0; k < PN; ++k) a = fmaf(p1[k], f2[(size_t)k * PN + g], a);
-            a = fmaxf(a, 0.0f);
-            if (kp) a = kp[PN + g] ? a * 2.0f : 0.0f;
-            xin[E + g] = a;
+        return a;
+    };
+    auto gather = [&](float4 a, int width, int col, int nch) {
+        for (int ch = 0; ch < nch; ++ch) {
+            const float4 q = part[ch * width + col];
+            a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
         }
-        __syncthreads();
-        {  // LSTM 1: rows [x (E+PN) ; h1 (H)]
-            float a0 = b1a, a1 = b1b;
-            const float* __restrict__ wc = w1 + g;
-            for (int k = 0; k < X; ++k) {
-                const float v = xin[k];
-                a0 = fmaf(v, wc[(size_t)k * G4], a0);
-                a1 = fmaf(v, wc[(size_t)k * G4 + 1024], a1);
-            }
-            wc += (size_t)X * G4;
-            for (int k = 0; k < H; ++k) {
-                const float v = h1[k];
-                a0 = fmaf(v, wc[(size_t)k * G4], a0);
-                a1 = fmaf(v, wc[(size_t)k * G4 + 1024], a1);
-            }
-            gates[g] = a0;
-            gates[g + 1024] = a1;
-        }
-        __syncthreads();
-        if (g < H) {
-            c1 = sigmoidf_(gates[2 * H + g] + 1.0f) * c1 + sigmoidf_(gates[g]) * tanhf(gates[H + g]);
-            h1[g] = sigmoidf_(gates[3 * H + g]) * tanhf(c1);
-        }
-        __syncthreads();
-        {  // LSTM 2: rows [h1 (H) ; x (E+PN) ; h2 (H)]
-            float a0 = b2a, a1 = b2b;
-            const float* __restrict__ wc = w2 + g;
-            for (int k = 0; k < H; ++k) {
-                const float v = h1[k];
-                a0 = fmaf(v, wc[(size_t)k * G4], a0);
-                a1 = fmaf(v, wc[(size_t)k * G4 + 1024], a1);
-            }
-            wc += (size_t)H * G4;
-            for (int k = 0; k < X; ++k) {
-                const float v = xin[k];
-                a0 = fmaf(v, wc[(size_t)k * G4], a0);
-                a1 = fmaf(v, wc[(size_t)k * G4 + 1024], a1);
-            }
-            wc += (size_t)X * G4;
-            for (int k = 0; k < H; ++k) {
-                const float v = h2[k];
-                a0 = fmaf(v, wc[(size_t)k * G4], a0);
-                a1 = fmaf(v, wc[(size_t)k * G4 + 1024], a1);
-            }
-            gates[g] = a0;  // LSTM 1's gate values were consumed before the barrier above
-            gates[g + 1024] = a1;
-        }
-        __syncthreads();
-        if (g < H) {
-            c2 = sigmoidf_(gates[2 * H + g] + 1.0f) * c2 + sigmoidf_(gates[g]) * tanhf(gates[H + g]);
-            h2[g] = sigmoidf_(gates[3 * H + g]) * tanhf(c2);
-        }
-        __syncthreads();
-        if (g < 8 * MEL) {  // projection: 8 partial dot products of 2H/8 terms per mel bin
-            const int m = g % MEL, ch = g / MEL, per = 2 * H / 8;
-            float a = 0.0f;
-            for (int k = ch * per; k < (ch + 1) * per; ++k) a = fmaf(k < H ? h1[k] : h2[k - H], wp[(size_t)k * MEL + m], a);
-            part[g] = a;
-        }
-        __syncthreads();
-        if (g < MEL) {
-            float a = bp[g];
-            for (int ch = 0; ch < 8; ++ch) a += part[ch * MEL + g];
-            prev[g] = a;
-            mel[((size_t)b * Fmax + f) * MEL + g] = a;
-        }
-        __syncthreads();
+        return a;
+    };
+    const int nchP = 1024 / MEL, perP = (2 * H + nchP - 1) / nchP;
+    if (g < nchP * MEL) part[g] = partial(hs, wp, 2 * H, MEL, g % MEL, g / MEL, perP);
+    __syncthreads();
+    if (g < MEL) {
+        const float bb = bp[g];
+        const float4 a = gather(make_float4(bb, bb, bb, bb), MEL, g, nchP);
+        prev[g] = a;
+        const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (f < nf[s]) mel[((size_t)(b0 + s) * Fmax + f) * MEL + g] = v[s];
     }
-    for (size_t i = g; i < (size_t)(Fmax - nf) * MEL; i += 1024) mel[((size_t)b * Fmax + nf) * MEL + i] = 0.0f;  // rows past the end
+    __syncthreads();
+    if (f + 1 >= Fmax) return;
+    auto masked = [&](float4 a, int which, int col) {  // relu, then hk.dropout(rate 0.5) with the given keep bytes of frame f + 1
+        float v[4] = {fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f), fmaxf(a.z, 0.0f), fmaxf(a.w, 0.0f)};
+        if (keep) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                if (b0 + s < B) v[s] = keep[(((size_t)(b0 + s) * Fmax + f + 1) * 2 + which) * PN + col] ? v[s] * 2.0f : 0.0f;
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    const int nchN = 1024 / PN;
+    if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, (MEL + nchN - 1) / nchN);
+    for (int e = g; e < E; e += 1024) {  // cond_{f+1} of the 4 sentences
+        float v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = b0 + s < B ? cond[((size_t)(b0 + s) * Fmax + f + 1) * E + e] : 0.0f;
+        *reinterpret_cast<float4*>(znext + (size_t)(H + e) * Bp + b0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    if (g < PN) p1[g] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 0, g);
+    __syncthreads();
+    if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, (PN + nchN - 1) / nchN);
+    __syncthreads();
+    if (g < PN) *reinterpret_cast<float4*>(znext + (size_t)(H + E + g) * Bp + b0) = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
 }
 
 // ---- shared host-side sequence: TokenEncoder of `m` under module prefix `te` -> enc [B][Lmax][2D] ------------------
@@ -610,8 +883,9 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
     if (!cfg || !out) return failf(VTTS_ERR_INVALID, "null argument");
     const int D = cfg->encoder_dim, V = cfg->vocab_size, H = cfg->decoder_dim, PN = cfg->prenet_dim, MEL = cfg->mel_dim, PD = cfg->postnet_dim;
     if (int rc = check_encoder_dims("acoustic model", D, V)) return rc;
-    if (H != 512 || PN < 1 || PN > 256 || MEL < 1 || MEL > 128 || PD < 1 || PD > 1024 || 2 * D + PN > 1024)
-        return failf(VTTS_ERR_INVALID, "acoustic model: decoder_dim must be 512 (two gate columns per thread of a 1024-thread workgroup), prenet_dim <= 256, mel_dim <= 128, postnet_dim <= 1024");
+    if (H < 32 || H > 1024 || H % 32 != 0 || PN < 32 || PN % 32 != 0 || MEL < 4 || MEL > 128 || MEL % 4 != 0 || PD < 4 || PD > 1024 || PD % 4 != 0 || 2 * D + PN > 1024)
+        return failf(VTTS_ERR_INVALID, "acoustic model: decoder_dim and prenet_dim must be multiples of 32 (matrix-core k-steps), decoder_dim <= 1024, "
+                                       "2 * encoder_dim + prenet_dim <= 1024, mel_dim <= 128 and postnet_dim <= 1024 multiples of 4");
     auto* h = new (std::nothrow) vtts_nat_acoustic();
     if (!h) return failf(VTTS_ERR_NOMEM, "host allocation failed");
     h->what = "acoustic model";
@@ -633,6 +907,38 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
         h->add("conv1_d" + sfx, "w", {5, cin, cout});
         h->add("conv1_d" + sfx, "b", {cout});
         if (i < 4) h->add_bn("batch_norm" + sfx, PD);
+    }
+    // postnet convolution weights in MFMA A-fragment order (nat_conv_mfma_k): [mblk][32-channel step][tap][lane][16]
+    for (int i = 0; i < 5; ++i) {
+        const std::string mod = "conv1_d" + (i ? "_" + std::to_string(i) : std::string());
+        const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD, MB = (cout + 31) / 32, NCS = (cin + 31) / 32;
+        h->add_extra(mod + "#mfma", (size_t)MB * NCS * 5 * 64 * 16 * sizeof(float), [mod, cin, cout, MB, NCS](const NatModel& m, float* out) {
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            for (int mb = 0; mb < MB; ++mb)
+                for (int cs = 0; cs < NCS; ++cs)
+                    for (int j = 0; j < 5; ++j)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 16; ++e) {
+                                const int c = 32 * cs + 16 * (lane >> 5) + e, co = 32 * mb + (lane & 31);
+                                out[((((size_t)mb * NCS + cs) * 5 + j) * 64 + lane) * 16 + e] = (c < cin && co < cout) ? W[((size_t)j * cin + c) * cout + co] : 0.0f;
+                            }
+        });
+    }
+    // decoder LSTM weights in MFMA A-fragment order (nat_dec_lstm_k): [slice = 8 units][K/8][lane][4],
+    // element i of lane = W[8*kb + 2*i + lane/32][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
+    for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
+        const std::string mod = l;
+        const int K = mod == "lstm/linear" ? X + H : H + X + H;
+        h->add_extra(mod + "#mfma", (size_t)K * 4 * H * sizeof(float), [mod, K, H](const NatModel& m, float* out) {
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            const int NIT = K / 8;
+            for (int sl = 0; sl < H / 8; ++sl)
+                for (int kb = 0; kb < NIT; ++kb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
+                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)(8 * kb + 2 * i + lh) * 4 * H + col];
+                    }
+        });
     }
     h->layout();
     *out = h;
@@ -665,6 +971,10 @@ VTTS_API int vtts_nat_acoustic_bind_packed(vtts_nat_acoustic* h, void* dev_blob,
     if (!h) return failf(VTTS_ERR_INVALID, "null argument");
     return h->bind(dev_blob, blob_bytes);
 }
+static size_t nat_dec_state_floats(const vtts_nat_acoustic_cfg& c, int B) {
+    const size_t Bp = (size_t)(B + 63) / 64 * 64, H = c.decoder_dim, ZW = 2 * H + 2 * (size_t)c.encoder_dim + c.prenet_dim;
+    return (2 * ZW + 2 * H) * Bp;
+}
 VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lmax, int Fmax, size_t* bytes) {
     if (!h || !bytes) return failf(VTTS_ERR_INVALID, "null argument");
     if (B <= 0 || Lmax <= 0 || Fmax <= 0) return failf(VTTS_ERR_INVALID, "B, Lmax and Fmax must be positive (got %d, %d, %d)", B, Lmax, Fmax);
@@ -672,7 +982,20 @@ VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B
     *bytes = 2 * align_up((size_t)B * Lmax * D * 4, 256) + align_up((size_t)B * Lmax * 2 * D * 4, 256)  // encoder ping-pong + output
              + align_up((size_t)B * Fmax * 2 * D * 4, 256)                                                 // cond
              + align_up((size_t)B * Fmax * MEL * 4, 256)                                                   // decoder mel
-             + 2 * align_up((size_t)B * Fmax * PD * 4, 256);                                               // postnet ping-pong
+             + 2 * align_up((size_t)B * Fmax * PD * 4, 256)                                                // postnet ping-pong
+             + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256);                                         // decoder state Z[2], c1, c2
+    return VTTS_OK;
+}
+VTTS_API int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint64_t* seeds_dev, int B, int Fmax, uint8_t* keep_dev, void* stream) {
+    if (!h || !seeds_dev || !keep_dev) return failf(VTTS_ERR_INVALID, "null argument");
+    if (B <= 0 || Fmax <= 0) return failf(VTTS_ERR_INVALID, "B and Fmax must be positive (got %d, %d)", B, Fmax);
+    const int PN = h->cfg.prenet_dim;
+    const size_t n = (size_t)B * Fmax * 2 * ((PN + 63) / 64);
+    const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+    hipLaunchKernelGGL(nat_keep_masks_k, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned long long*>(seeds_dev),
+                       keep_dev, B, Fmax, PN);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return failf(VTTS_ERR_HIP, "keep-mask launch failed: %s", hipGetErrorString(e));
     return VTTS_OK;
 }
 VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
@@ -701,26 +1024,59 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
     float* mel0 = take((size_t)B * Fmax * MEL * 4);
     float* pA = take((size_t)B * Fmax * PD * 4);
     float* pB = take((size_t)B * Fmax * PD * 4);
+    float* dstate = take(nat_dec_state_floats(h->cfg, B) * 4);
     rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, enc, s);  // model.py:131
     if (rc) return rc;
     hipLaunchKernelGGL(nat_upsample_k, dim3(Fmax, B), dim3(256), (2 * Lmax + 8) * sizeof(float), s, enc, lengths_dev, durations_dev, nframes_dev, cond,
                        Lmax, Fmax, E);  // :132
-    const size_t dec_lds = ((size_t)(E + PN) + 2 * H + 4 * H + MEL + PN + 8 * MEL) * sizeof(float);
-    hipLaunchKernelGGL(nat_decoder_k, dim3(B), dim3(1024), dec_lds, s, cond, nframes_dev, h->dev("linear_1", "w"), h->dev("linear_2", "w"),
-                       h->dev("lstm/linear", "w"), h->dev("lstm/linear", "b"), h->dev("lstm_1/linear", "w"), h->dev("lstm_1/linear", "b"),
-                       h->dev("linear", "w"), h->dev("linear", "b"), keep_dev, mel0, Fmax, E, PN, H, MEL);  // :134-150
+    {  // autoregressive decoder (:134-150): per frame LSTM1, LSTM2, projection + next frame's prenet, all sentences at once
+        const int Bp = (B + 63) / 64 * 64, X = E + PN, ZW = 2 * H + X;
+        float* Z[2] = {dstate, dstate + (size_t)ZW * Bp};
+        float* c1 = dstate + 2 * (size_t)ZW * Bp;
+        float* c2 = c1 + (size_t)H * Bp;
+        HIP_TRYN(hipMemsetAsync(dstate, 0, nat_dec_state_floats(h->cfg, B) * 4, s));
+        HIP_TRYN(hipMemsetAsync(mel0, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame stay zero
+        hipLaunchKernelGGL(nat_dec_init_k, dim3(B), dim3(256), 0, s, cond, Z[0] + (size_t)H * Bp, B, Bp, Fmax, E);
+        const float4* w1 = reinterpret_cast<const float4*>(h->extra("lstm/linear#mfma"));
+        const float4* w2 = reinterpret_cast<const float4*>(h->extra("lstm_1/linear#mfma"));
+        const float *b1 = h->dev("lstm/linear", "b"), *b2 = h->dev("lstm_1/linear", "b");
+        const float *f1 = h->dev("linear_1", "w"), *f2 = h->dev("linear_2", "w"), *wp = h->dev("linear", "w"), *bp = h->dev("linear", "b");
+        const bool wide = B > 32;  // two 32-sentence tiles per wave once there are that many sentences
+        const dim3 lgrid(H / 8, wide ? Bp / 64 : 1);
+        auto lstm = [&](const float* inA, int KA, const float* inB, const float4* w, const float* bias, float* cst, float* hout, int f) {
+            if (wide)
+                hipLaunchKernelGGL((nat_dec_lstm_k<2, 8>), lgrid, dim3(512), 0, s, inA, KA, inB, H, w, bias, cst, hout, nframes_dev, f, B, Bp, H);
+            else
+                hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, inA, KA, inB, H, w, bias, cst, hout, nframes_dev, f, B, Bp, H);
+        };
+        const size_t plds = ((size_t)2 * H + 1024 + MEL + PN) * sizeof(float4);
+        for (int f = 0; f < Fmax; ++f) {
+            float* zc = Z[f & 1];
+            float* zp = Z[(f + 1) & 1];
+            lstm(zc + (size_t)H * Bp, X, zp, w1, b1, c1, zc, f);
+            lstm(zc, H + X, zp + (size_t)(H + X) * Bp, w2, b2, c2, zc + (size_t)(H + X) * Bp, f);
+            hipLaunchKernelGGL(nat_dec_proj_prenet_k, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, cond, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f,
+                               B, Bp, Fmax, E, PN, H, MEL);
+        }
+    }
     // postnet (:113-121) + residual (:151): 4 x (Conv1D(PD, 5) + BatchNorm + tanh), Conv1D(MEL, 5), mel + .
-    constexpr int TL = 8;
+    HIP_TRYN(hipMemsetAsync(mel_dev, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame
     const float* cur = mel0;
     float* bufs[2] = {pA, pB};
     for (int i = 0; i < 5; ++i) {
         const std::string sfx = i ? "_" + std::to_string(i) : "";
         const std::string cv = "conv1_d" + sfx, bn = "batch_norm" + sfx;
-        const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD;
+        const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD, MB = (cout + 31) / 32;
         float* dst = i == 4 ? mel_dev : bufs[i & 1];
-        hipLaunchKernelGGL((nat_conv_bn_act_k<5, TL>), dim3((Fmax + TL - 1) / TL, B), dim3(256), (TL + 4) * cin * sizeof(float), s, cur, nframes_dev,
-                           h->dev(cv, "w"), h->dev(cv, "b"), i < 4 ? h->inv(bn) : nullptr, i < 4 ? h->dev(bn + "/~/mean_ema", "average") : nullptr,
-                           i < 4 ? h->dev(bn, "offset") : nullptr, i == 4 ? mel0 : nullptr, dst, Fmax, cin, cout, i < 4 ? (int)NAT_ACT_TANH : (int)NAT_ACT_NONE);
+        const float4* wpk = reinterpret_cast<const float4*>(h->extra(cv + "#mfma"));
+        const float *iv = i < 4 ? h->inv(bn) : nullptr, *mv = i < 4 ? h->dev(bn + "/~/mean_ema", "average") : nullptr, *ov = i < 4 ? h->dev(bn, "offset") : nullptr;
+        const int act = i < 4 ? (int)NAT_ACT_TANH : (int)NAT_ACT_NONE;
+        if (MB >= 8)
+            hipLaunchKernelGGL((nat_conv_mfma_k<5, 2>), dim3((Fmax + 63) / 64, (MB + 7) / 8, B), dim3(256), 0, s, cur, nframes_dev, wpk, h->dev(cv, "b"), iv, mv,
+                               ov, i == 4 ? mel0 : nullptr, dst, Fmax, cin, cout, act);
+        else
+            hipLaunchKernelGGL((nat_conv_mfma_k<5, 1>), dim3((Fmax + 63) / 64, (MB + 3) / 4, B), dim3(256), 0, s, cur, nframes_dev, wpk, h->dev(cv, "b"), iv, mv,
+                               ov, i == 4 ? mel0 : nullptr, dst, Fmax, cin, cout, act);
         cur = dst;
     }
     hipError_t e = hipGetLastError();

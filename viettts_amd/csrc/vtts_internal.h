@@ -76,7 +76,9 @@ struct BConvArgs {
     const float* bias;    // fp32 [COUTP]
     const void* res;      // optional residual, bf16 [B][L][COUTP], or nullptr
     void* y;              // output bf16 [B][L][COUTP]
-    int B, L;
+    int B, L;             // utterances; rows (time steps) ALLOCATED per utterance in x / y
+    const int* lens;      // ragged batch: valid mel frames per utterance (device, [B]) or nullptr = all L rows valid
+    int len_mul;          // rows of this layer per mel frame (valid rows of utterance b = lens[b] * len_mul)
     int x_pitch;          // elements per input row in global memory
     int cin_real;         // valid input channels (conv_pre: 80)
     int dil, pad;

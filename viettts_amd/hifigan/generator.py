@@ -164,6 +164,33 @@ class Generator:
             )
         return out
 
+    def forward_ragged(self, mel: torch.Tensor, frames, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Utterances of different lengths in one batch (bf16 engine): ``mel`` ``[B, Tmax, num_mels]`` with utterance b's
+        ``frames[b]`` frames at the start of its slot.  ``out[b, :hop*frames[b]]`` equals ``self(mel[b:b+1, :frames[b]])``
+        bit for bit; the rest of the row is zero.  ``frames``: int sequence or int32 tensor on the device."""
+        mel = self._check_mel(mel)
+        B, T, _ = mel.shape
+        if isinstance(frames, torch.Tensor):
+            fr = frames.to(device=self.device, dtype=torch.int32).contiguous()
+            fr_host = None
+        else:
+            fr_host = [int(v) for v in frames]
+            fr = torch.tensor(fr_host, dtype=torch.int32, device=self.device)
+        if fr.numel() != B or (fr_host is not None and (min(fr_host) < 1 or max(fr_host) > T)):
+            raise ValueError("frames must hold one count per utterance, 1 <= frames[b] <= mel.shape[1]")
+        if out is None:
+            out = torch.empty((B, self.hop * T), dtype=torch.float32, device=self.device)
+        elif out.shape != (B, self.hop * T) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != self.device:
+            raise ValueError("out must be a contiguous float32 [B, hop*T] tensor on the generator's device")
+        ws = self._workspace(B, T)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib,
+                self.lib.vtts_hifigan_forward_ragged(self._h, _ptr(mel), _ptr(fr), B, T, _ptr(out), _ptr(ws), ws.numel(), C.c_void_p(stream.cuda_stream)),
+            )
+        return out
+
     def forward_tap(self, mel: torch.Tensor, tap: str):
         """(wav, tap tensor) — test hook; tap in {"conv_pre","ups_i","mrf_i","pre_tanh"}."""
         mel = self._check_mel(mel)

@@ -7,8 +7,9 @@ provides device memory and the stream.  There is no CPU path.
 
 The prenet's dropout is on at inference in the reference (model.py:95-100) and draws from JAX's threefry PRNG through
 Haiku's per-scan-step key splitting; that stream is not restated here.  ``keep_masks`` (boolean ``[n_frames, 2, 256]`` per
-sentence) makes the dropout explicit; ``None`` runs without dropout.  :func:`bernoulli_keep_masks` draws reproducible masks
-from numpy's PCG64 (rate 0.5, the reference's rate) — statistically, not bitwise, the reference's behaviour.
+sentence) makes the dropout explicit; ``dropout_seeds`` has the library draw the masks on the GPU (Threefry-2x32-20, one
+seed per sentence: the product path, nothing crosses PCIe); neither runs without dropout.  :func:`bernoulli_keep_masks`
+draws host masks from numpy's PCG64 for tests.  All of these are statistically, not bitwise, the reference's behaviour.
 """
 from __future__ import annotations
 
@@ -82,9 +83,22 @@ class AcousticModel:
             _lib.check(self.lib, self.lib.vtts_nat_acoustic_pack(self._h, _ptr(blob), blob.numel(), C.c_void_p(stream.cuda_stream)))
         self._blob = blob
 
+    def device_keep_masks(self, seeds: Sequence[int], Fmax: int) -> torch.Tensor:
+        """``[B, Fmax, 2, prenet_dim]`` uint8 keep masks drawn on the GPU (include/vtts_nat.h: Threefry-2x32-20, one
+        64-bit seed per sentence; oracle/nat_oracle.py::threefry_keep_masks is the CPU restatement)."""
+        B = len(seeds)
+        sd = torch.tensor([int(x) & 0x7FFFFFFFFFFFFFFF for x in seeds], dtype=torch.int64, device=self.device)
+        keep = torch.empty((B, int(Fmax), 2, self.prenet_dim), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks(self._h, _ptr(sd), B, int(Fmax), _ptr(keep), C.c_void_p(stream.cuda_stream)))
+        return keep
+
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
-                 keep_masks: Optional[Sequence[np.ndarray]] = None) -> List[np.ndarray]:
-        """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``."""
+                 keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None) -> List[np.ndarray]:
+        """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``.
+        Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_seeds`` (one int per sentence: masks drawn on the
+        GPU), or neither (no dropout)."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
         B = len(sentences)
@@ -103,6 +117,10 @@ class AcousticModel:
             for i, m in enumerate(keep_masks):
                 keep[i, : n_frames[i]] = np.asarray(m, dtype=bool)[: n_frames[i]]
             keep_d = torch.from_numpy(keep).to(self.device)
+        elif dropout_seeds is not None:
+            if len(dropout_seeds) != B:
+                raise ValueError("one dropout seed per sentence")
+            keep_d = self.device_keep_masks(dropout_seeds, Fmax)
         tok_d = torch.from_numpy(tok).to(self.device)
         dur_d = torch.from_numpy(dur).to(self.device)
         len_d = torch.tensor(lens, dtype=torch.int32, device=self.device)

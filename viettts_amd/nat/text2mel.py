@@ -12,9 +12,9 @@ What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
 
   * ``predict_mel(tokens, durations)`` (:61-82) on the MI355X: the acoustic network's inference path
     (vietTTS/nat/model.py:128-151) behind the same header (viettts_amd/nat/acoustic.py).  The reference's prenet
-    dropout is ON at inference and draws from JAX's threefry PRNG with the checkpoint's key; that stream is not
-    restated: ``predict_mel`` draws its keep masks (rate 0.5) from numpy's PCG64 seeded by ``dropout_seed`` —
-    statistically, not bitwise, the reference's mel.
+    dropout is ON at inference and draws from JAX's threefry PRNG through Haiku's per-step splitting of the
+    checkpoint's key; that stream is not restated: ``predict_mel`` has the library draw its keep masks (rate 0.5) on
+    the GPU from ``dropout_seed`` (Threefry-2x32-20, include/vtts_nat.h) — statistically, not bitwise, the reference's mel.
 
 ``text2mel`` uses a registered mel provider (:func:`set_mel_provider`; tests and the CLI's ``--mel-file``) if there is
 one, else the two networks, loading ``duration_latest_ckpt.pickle`` / ``acoustic_latest_ckpt.pickle`` from
@@ -166,12 +166,8 @@ def predict_mel(tokens: Sequence[int], durations: np.ndarray, dropout_seed: Opti
     n_frames = n_frames_from_durations(durations)  # :79
     if n_frames < 1:
         return np.zeros((1, 0, FLAGS.mel_dim), dtype=np.float32)
-    keep = None
-    if dropout_seed is not None:
-        from .acoustic import bernoulli_keep_masks
-
-        keep = [bernoulli_keep_masks(n_frames, dropout_seed)]
-    return _ACOUSTIC_MODEL([list(tokens)], [frames[0]], [n_frames], keep_masks=keep)[0][None]
+    seeds = None if dropout_seed is None else [dropout_seed]  # masks drawn on the GPU (include/vtts_nat.h)
+    return _ACOUSTIC_MODEL([list(tokens)], [frames[0]], [n_frames], dropout_seeds=seeds)[0][None]
 
 
 _MEL_PROVIDER: Optional[Callable] = None
