@@ -85,6 +85,51 @@ def pmc_traffic(kernel: str, args, B: int, T: int):
             "source": rec["source"]}
 
 
+def pipeline_256(n=256, gen=None):
+    """BASELINE.json configs[3] on this GPU: n synthetic sentences (synthetic checkpoints; token statistics of lexicon
+    output) -> NAT duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) ->
+    HiFi-GAN bf16 in ragged batches.  Second pass timed, device-synchronised per stage, host work included."""
+    import time
+
+    import torch
+
+    from viettts_amd.hifigan.config import V1
+    from viettts_amd.hifigan.generator import Generator
+    from viettts_amd.hifigan.synth import synthetic_params
+    from viettts_amd.nat.acoustic import AcousticModel
+    from viettts_amd.nat.duration import DurationModel
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint, synthetic_duration_checkpoint, synthetic_sentences
+    from viettts_amd.pipeline import synthesize_sentences
+
+    own = gen is None
+    if own:
+        gen = Generator(V1, device="cuda:0", dtype="bf16")
+        gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    dm = DurationModel(device=str(gen.device))
+    dm.load_params(*synthetic_duration_checkpoint())
+    am = AcousticModel(device=str(gen.device))
+    am.load_params(*synthetic_acoustic_checkpoint())
+    sents = synthetic_sentences(n)
+    out = {}
+    for _ in range(2):  # the first pass warms allocators and code objects
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        wavs = synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, dropout_seed=7, timing=tm)
+        torch.cuda.synchronize()
+        total = time.perf_counter() - t0
+        nsamp = int(sum(w.shape[0] for w in wavs.values()))
+        out = {"workload": f"{n} synthetic sentences, text tokens -> 16 kHz waveform, this GPU only", "sentences": n, "tokens": tm["tokens"],
+               "frames": tm["frames"], "frames_max": tm["frames_max"], "samples": nsamp, "duration_model_ms": tm["duration_s"] * 1e3,
+               "host_rules_ms": tm["host_rules_s"] * 1e3, "acoustic_model_ms": tm["acoustic_s"] * 1e3, "generator_ms": tm["generator_s"] * 1e3,
+               "total_ms": total * 1e3, "samples_per_s": nsamp / total, "sentences_per_s": n / total}
+    dm.close()
+    am.close()
+    if own:
+        gen.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -270,6 +315,9 @@ def main():
                 "rtf_16000": tm["total_s"] / 600.0,
                 "chunks": tm["chunks"],
             }
+        # ---- text -> waveform (BASELINE configs[3]): 256 sentences through duration model, acoustic model, generator ----
+        if not args.no_rtf:
+            res["pipeline_256"] = pipeline_256(256, gen)
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

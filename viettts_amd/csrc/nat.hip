@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
 // 16-byte load per lane feeds 4 MFMAs ([slice][K/8][lane][4]: element i = W[8*kb + 2*i + lane/32][col(lane%32)]);
 // activations straight from Z (128-byte rows, L2-resident); both PD iterations (8 k each) ahead in registers.
 // Every output element depends on its own sentence's column only: rows are bit-identical alone or batched.
-constexpr int NAT_DEC_PD = 4;   // iterations (8 k each) a wave keeps in flight
+constexpr int NAT_DEC_PD = 4;   // iterations (8 k each) a wave keeps in flight (7 measured no faster: the step is L2-bandwidth-bound)
 
 // NT = 32-sentence tiles per wave (one weight fragment feeds NT MFMAs: L2 traffic for the weights / NT), KW = waves per
 // workgroup, each with a contiguous share of K; their partial sums meet in LDS in a fixed tree order.

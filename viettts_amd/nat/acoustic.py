@@ -95,10 +95,11 @@ class AcousticModel:
         return keep
 
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
-                 keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None) -> List[np.ndarray]:
+                 keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None, to_host: bool = True):
         """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``.
         Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_seeds`` (one int per sentence: masks drawn on the
-        GPU), or neither (no dropout)."""
+        GPU), or neither (no dropout).  ``to_host=False`` returns the device tensor ``[B, Fmax, mel_dim]`` (rows past a
+        sentence's ``n_frames`` are zero) instead of per-sentence host arrays: the generator's input stays in HBM."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
         B = len(sentences)
@@ -137,5 +138,7 @@ class AcousticModel:
                 self.lib.vtts_nat_acoustic_forward(self._h, _ptr(tok_d), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d), _ptr(out),
                                                    _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream)),
             )
+        if not to_host:
+            return out
         host = out.cpu().numpy()
         return [host[i, : n_frames[i]].copy() for i in range(B)]

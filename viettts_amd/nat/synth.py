@@ -78,3 +78,19 @@ def synthetic_acoustic_checkpoint(seed: int = 778, vocab_size: int = FLAGS.vocab
         if i < 4:
             bn(pre + "batch_norm" + sfx, post)
     return P, S
+
+
+def synthetic_sentences(n: int = 256, seed: int = 2024):
+    """Token-id lists shaped like lexicon output (sil, words of 2-5 phonemes each closed by the word-end token, sil):
+    6-21 words per sentence.  BASELINE.json configs[3] names 256 InfoRe sentences; transcripts and lexicon do not
+    travel to the GPU box, the token statistics do."""
+    from .config import FLAGS
+
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        body = []
+        for _ in range(int(rng.integers(6, 22))):
+            body += [int(v) for v in rng.integers(4, 90, size=int(rng.integers(2, 6)))] + [FLAGS.word_end_index]
+        out.append([FLAGS.sil_index] + body + [FLAGS.sil_index])
+    return out

@@ -22,13 +22,30 @@ from .nat.config import FLAGS
 
 
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
-                         dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 64) -> Dict[int, np.ndarray]:
-    """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index."""
+                         dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 64,
+                         timing: Optional[dict] = None) -> Dict[int, np.ndarray]:
+    """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index.  ``timing`` (a dict) receives
+    device-synchronised wall seconds per stage."""
+    import time
+
+    def mark(name, t_prev):
+        if timing is None:
+            return t_prev
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        timing[name] = timing.get(name, 0.0) + now - t_prev
+        return now
+
     mine = shard_utterances([len(t) for t in token_lists], world)[rank]
     if not mine:
         return {}
+    t_last = 0.0
+    if timing is not None:
+        torch.cuda.synchronize()
+        t_last = time.perf_counter()
     toks = [list(token_lists[i]) for i in mine]
     secs = duration_model(toks)  # [L] seconds per token each
+    t_last = mark("duration_s", t_last)
     frames, nfr, trail = [], [], []
     for t, d in zip(toks, secs):
         d = t2m.apply_duration_rules(t, d[None, :], silence_duration)  # text2mel.py:90-97
@@ -36,29 +53,42 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         nfr.append(t2m.n_frames_from_durations(d))  # :79
         trail.append(t2m.trailing_silence_frames(d) if t[-1] == FLAGS.sil_index else 0)  # :99-101
     ok = [k for k, n in enumerate(nfr) if n >= 1]
-    mels: List[Optional[np.ndarray]] = [None] * len(mine)
-    if ok:
-        # prenet dropout (on at inference, model.py:95-100): masks drawn on the GPU, seeded by the sentence's GLOBAL index
-        out = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok],
-                             dropout_seeds=None if dropout_seed is None else [dropout_seed + mine[k] for k in ok])
-        for k, m in zip(ok, out):
-            mels[k] = m[: m.shape[0] - trail[k]] if trail[k] else m  # :102
-    # the generator takes ragged batches (vtts_hifigan_forward_ragged: each utterance's samples are those of running it
-    # alone): sentences sorted by length, dealt into batches of at most `gen_batch`, padded to the batch's longest
-    todo = sorted((k for k, m in enumerate(mels) if m is not None and m.shape[0] > 0), key=lambda k: mels[k].shape[0])
+    t_last = mark("host_rules_s", t_last)
     wavs: Dict[int, np.ndarray] = {}
-    ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
-    for i0 in range(0, len(todo), gen_batch if ragged else 1):
-        ks = todo[i0 : i0 + (gen_batch if ragged else 1)]
-        fr = [mels[k].shape[0] for k in ks]
-        batch = np.zeros((len(ks), max(fr), mels[ks[0]].shape[1]), dtype=np.float32)
-        for r, k in enumerate(ks):
-            batch[r, : fr[r]] = mels[k]
-        dev = torch.from_numpy(batch).to(generator.device)
-        w = (generator.forward_ragged(dev, fr) if ragged else generator(dev)).cpu().numpy()
-        for r, k in enumerate(ks):
-            wavs[mine[k]] = w[r, : generator.hop * fr[r]].copy()
-    for k, m in enumerate(mels):
+    gfr = {k: nfr[k] - trail[k] for k in ok}  # frames the generator sees: the mel minus its trailing silence (:102)
+    if ok:
+        # prenet dropout (on at inference, model.py:95-100): masks drawn on the GPU, seeded by the sentence's GLOBAL index.
+        # The mel stays in HBM: [len(ok), Fmax, 80] on the device, rows past a sentence's frames zero.
+        mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok],
+                                 dropout_seeds=None if dropout_seed is None else [dropout_seed + mine[k] for k in ok], to_host=False)
+        t_last = mark("acoustic_s", t_last)
+        # the generator takes ragged batches (vtts_hifigan_forward_ragged: each utterance's samples are those of running it
+        # alone): sentences sorted by length, dealt into batches of at most `gen_batch`, cut to the batch's longest
+        ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
+        todo = sorted((r for r, k in enumerate(ok) if gfr[k] > 0), key=lambda r: gfr[ok[r]])
+        step = gen_batch if ragged else 1
+        pending = []
+        for i0 in range(0, len(todo), step):
+            rows = todo[i0 : i0 + step]
+            fr = [gfr[ok[r]] for r in rows]
+            batch = mel_dev[torch.tensor(rows, device=mel_dev.device), : max(fr)].contiguous()  # a device-side gather (plumbing)
+            w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
+            host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
+            host.copy_(w, non_blocking=True)  # pinned, stream-ordered: the next batch computes behind this copy's enqueue
+            pending.append((rows, fr, host))
+        torch.cuda.synchronize()
+        for rows, fr, host in pending:
+            hn = host.numpy()
+            for q, r in enumerate(rows):
+                wavs[mine[ok[r]]] = hn[q, : generator.hop * fr[q]]  # a view of the batch's pinned buffer (kept alive by the view)
+    else:
+        t_last = mark("acoustic_s", t_last)
+    t_last = mark("generator_s", t_last)
+    if timing is not None:
+        timing["frames"] = int(sum(gfr.values()))
+        timing["frames_max"] = int(max(list(gfr.values()) or [0]))
+        timing["tokens"] = int(sum(len(t) for t in toks))
+    for k in range(len(mine)):
         if mine[k] not in wavs:
             wavs[mine[k]] = np.zeros((0,), np.float32)
     return wavs
