@@ -13,11 +13,11 @@
 //     workgroups read the same 2 MB), [x_t ; h] broadcast from LDS, cell state in registers of the first D threads;
 //   * head: Linear(2D -> D) + tanh-form gelu + Linear(D -> 1) + softplus per token, block reduction for the last dot.
 // Acoustic model (model.py:73-151, inference path): the same TokenEncoder, Gaussian upsampling to frames (one block per
-// frame), the autoregressive decoder as ONE persistent 1024-thread workgroup per sentence (prenet, two LSTM-512 with skip
-// connections, mel projection; every thread owns two gate columns; the 25 MB of weights stream from L2 / Infinity Cache each
-// frame — a functional first cut: the weights-stationary form, gate columns spread over all CUs with a grid barrier per
-// frame, is what comes next), then the 5-layer postnet with the generic Conv1D + BatchNorm + activation kernel.
-// The prenet's always-on dropout (model.py:95-100) takes explicit keep masks: JAX's threefry stream is not restated.
+// frame), the autoregressive decoder as one launch per layer per frame over ALL sentences of the batch (two LSTM-512 with
+// skip connections on the fp32 matrix cores, cell update in registers; mel projection + next frame's prenet), then the
+// 5-layer postnet as fp32 MFMA convolutions.
+// The prenet's always-on dropout (model.py:95-100) takes explicit keep masks, which vtts_nat_acoustic_keep_masks can draw on
+// the device with jax.random's cipher (Threefry-2x32-20); Haiku's key-splitting schedule is not restated.
 #include "../../include/vtts_nat.h"
 
 #include <hip/hip_runtime.h>
