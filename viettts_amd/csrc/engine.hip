@@ -404,6 +404,7 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
     a.cin_real = cin_real;
     a.dil = (l.kind == KIND_CONVT) ? 1 : l.dil;
     a.pad = (l.kind == KIND_CONVT) ? 1 : l.pad;
+    a.convt_halves = (l.kind == KIND_CONVT) ? 1 : 0;
     a.slope_in = slope_in;
     a.slope_out = slope_out;
     a.acc_add = acc_add;

@@ -166,23 +166,32 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         }
     };
 
-    issue_slab(0, 0);
+    // A transposed convolution run as Conv1d(k = 3) has one structurally zero tap per output phase (engine.hip: phases
+    // r < s/2 read frames q-1, q = taps 0, 1; the others q, q+1 = taps 1, 2): an M tile inside one half of the rows skips
+    // that tap's slabs altogether (a third of its MFMAs and weight traffic).
+    const bool halves = a.convt_halves != 0 && KS == 3 && TG == 1 && (COUTP / 2) % MT == 0;
+    const int tap0 = (halves && mtile * MT >= COUTP / 2) ? 1 : 0;
+    const int nsl = halves ? 2 : NSL;            // slabs (taps) visited per channel chunk
+    const int nit = NXC * NCK * nsl;             // ... per workgroup
+    auto slab_of = [&](int it) { return (it / nsl) * NSL + tap0 + it % nsl; };
+    issue_slab(slab_of(0), 0);
     stage_x(0);
     __syncthreads();  // also drains the LDS-DMA (the barrier's release waits vmcnt(0))
 
     const int dil = a.dil;
     const int rowbase0 = wn * (NT / WN) + l31 - a.pad + PA;
-    int s = 0;
+    int s = 0;  // slabs visited so far
     for (int xc = 0; xc < NXC; ++xc) {
         if (xc > 0) {
             stage_x(xc);  // every wave passed the barrier that ended the previous slab: the old X is dead
             __syncthreads();
         }
         for (int ck = 0; ck < NCK; ++ck) {
-            for (int sl = 0; sl < NSL; ++sl, ++s) {
-                // slab s+1 streams into the other buffer while slab s feeds the MFMAs; every wave is past the
-                // barrier that ended slab s-1, so nobody still reads that buffer
-                if ((s + 1) < NSTOT) issue_slab(s + 1, (s + 1) & 1);
+            for (int sli = 0; sli < nsl; ++sli, ++s) {
+                const int sl = tap0 + sli;
+                // the next slab streams into the other buffer while this one feeds the MFMAs; every wave is past the
+                // barrier that ended the previous one, so nobody still reads that buffer
+                if ((s + 1) < nit) issue_slab(slab_of(s + 1), (s + 1) & 1);
                 const unsigned char* abuf = ab + (T::NBUF == 2 ? (s & 1) * T::SLAB_BYTES : 0) + (size_t)(wm * MR) * 1024 + lane * 16;
                 const int ntaps = (KS - sl * TG) < TG ? (KS - sl * TG) : TG;
                 const int slot0 = ck * (CKC / 8) + lh;

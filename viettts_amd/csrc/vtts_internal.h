@@ -82,6 +82,7 @@ struct BConvArgs {
     int x_pitch;          // elements per input row in global memory
     int cin_real;         // valid input channels (conv_pre: 80)
     int dil, pad;
+    int convt_halves;     // conv_bf16_k on a transposed convolution's 3-tap form: skip each row half's all-zero tap
     int dils[3];          // whole-ResBlock kernel: the three pairs' rates
     float slope_in;       // LeakyReLU applied to the input while staging (1 = producer already did it)
     float slope_out;      // LeakyReLU applied to the stored output (the consumer's activation), 1 = none
