@@ -85,10 +85,11 @@ def pmc_traffic(kernel: str, args, B: int, T: int):
             "source": rec["source"]}
 
 
-def pipeline_256(n=256, gen=None):
-    """BASELINE.json configs[3] on this GPU: n synthetic sentences (synthetic checkpoints; token statistics of lexicon
-    output) -> NAT duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) ->
-    HiFi-GAN bf16 in ragged batches.  Second pass timed, device-synchronised per stage, host work included."""
+def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
+    """BASELINE.json configs[3]: n synthetic sentences (synthetic checkpoints; token statistics of lexicon output) -> NAT
+    duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) -> HiFi-GAN bf16 in
+    ragged batches; this rank's shard of the sentences (viettts_amd.dist.shard_utterances; no exchange step).  Second pass
+    timed, device-synchronised per stage, host work included.  Returns this rank's numbers; main() combines the ranks."""
     import time
 
     import torch
@@ -114,15 +115,17 @@ def pipeline_256(n=256, gen=None):
     for _ in range(2):  # the first pass warms allocators and code objects
         tm = {}
         torch.cuda.synchronize()
+        if barrier:
+            barrier()
         t0 = time.perf_counter()
-        wavs = synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, dropout_seed=7, timing=tm)
+        wavs = synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, dropout_seed=7, rank=rank, world=world, timing=tm)
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
         nsamp = int(sum(w.shape[0] for w in wavs.values()))
-        out = {"workload": f"{n} synthetic sentences, text tokens -> 16 kHz waveform, this GPU only", "sentences": n, "tokens": tm["tokens"],
-               "frames": tm["frames"], "frames_max": tm["frames_max"], "samples": nsamp, "duration_model_ms": tm["duration_s"] * 1e3,
-               "host_rules_ms": tm["host_rules_s"] * 1e3, "acoustic_model_ms": tm["acoustic_s"] * 1e3, "generator_ms": tm["generator_s"] * 1e3,
-               "total_ms": total * 1e3, "samples_per_s": nsamp / total, "sentences_per_s": n / total}
+        out = {"workload": f"{n} synthetic sentences, text tokens -> 16 kHz waveform, sharded over {world} GPU(s) with no exchange step",
+               "sentences": n, "tokens": tm.get("tokens", 0), "frames": tm.get("frames", 0), "frames_max": tm.get("frames_max", 0), "samples": nsamp,
+               "duration_model_ms": tm.get("duration_s", 0.0) * 1e3, "host_rules_ms": tm.get("host_rules_s", 0.0) * 1e3,
+               "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3, "generator_ms": tm.get("generator_s", 0.0) * 1e3, "total_ms": total * 1e3}
     dm.close()
     am.close()
     if own:
@@ -192,8 +195,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if not os.environ.get("VTTS_BENCH_ALLOW_GARBAGE"):  # set only for timing-ablation builds
-        assert bool(torch.isfinite(out[0, :4096]).all()), "non-finite output"
+    # ---- text -> waveform (BASELINE configs[3]): 256 sentences sharded over the ranks; whole job = max over ranks ----
+    pipe = None
+    if not args.no_rtf and args.dtype == "bf16":
+        pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier)
+        if n_gpus > 1:
+            keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "generator_ms", "total_ms", "frames_max"]
+            keys_sum = ["tokens", "frames", "samples"]
+            tmax = torch.tensor([float(pipe[k]) for k in keys_max], dtype=torch.float64, device=dev)
+            tsum = torch.tensor([float(pipe[k]) for k in keys_sum], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            for k, v in zip(keys_max, tmax.tolist()):
+                pipe[k] = v
+            for k, v in zip(keys_sum, tsum.tolist()):
+                pipe[k] = int(v)
+        pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
+        pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
+
+    assert bool(torch.isfinite(out[0, :4096]).all()), "non-finite output"
 
     if info.rank == 0:
         samples_per_step = n_gpus * B * 256 * T
@@ -315,9 +335,8 @@ def main():
                 "rtf_16000": tm["total_s"] / 600.0,
                 "chunks": tm["chunks"],
             }
-        # ---- text -> waveform (BASELINE configs[3]): 256 sentences through duration model, acoustic model, generator ----
-        if not args.no_rtf:
-            res["pipeline_256"] = pipeline_256(256, gen)
+        if pipe is not None:
+            res["pipeline_256"] = pipe
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

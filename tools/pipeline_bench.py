@@ -9,4 +9,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import pipeline_256  # noqa: E402
 
 if __name__ == "__main__":
-    print(json.dumps(pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256)))
+    r = pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256)
+    r["samples_per_s"] = r["samples"] / (r["total_ms"] * 1e-3)
+    print(json.dumps(r))

@@ -31,20 +31,6 @@
 
 #include "bf16_common.h"
 
-// timing ablations (never defined in the product build): results are wrong when any is set
-#ifndef VTTS_EXP_NOSTORE
-#define VTTS_EXP_NOSTORE 0
-#endif
-#ifndef VTTS_EXP_NOXLOAD
-#define VTTS_EXP_NOXLOAD 0
-#endif
-#ifndef VTTS_EXP_NOMFMA
-#define VTTS_EXP_NOMFMA 0
-#endif
-#ifndef VTTS_EXP_NOSLAB
-#define VTTS_EXP_NOSLAB 0
-#endif
-
 namespace vtts {
 
 template <int CINP_, int XC_, int CKC_, int COUTP_, int KS_, int MT_, int NT_, int WM_, int WN_, int TG_, int PA_, bool IN_F32_>
@@ -123,7 +109,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int u0 = wave * 64 + i * THREADS;  // wave-uniform
-            if (!VTTS_EXP_NOSLAB && (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS))
+            if (APT * THREADS == T::SLAB_UNITS || u0 < T::SLAB_UNITS)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + u0 + lane), (lds_ptr_t)(dst + (size_t)i * THREADS * 16), 16, 0, 0);
         }
     };
@@ -135,7 +121,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
             const int row = u / SPR, c = u % SPR;
             const int t = t0 - PA + row;
             v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (!VTTS_EXP_NOXLOAD && u < ROWS * SPR && t >= 0 && t < L) {
+            if (u < ROWS * SPR && t >= 0 && t < L) {
                 const int ch = cc * XC + c * 8;
                 if constexpr (T::IN_F32) {
                     if (ch < a.cin_real) {
@@ -234,8 +220,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
                         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                             for (int nr = 0; nr < NR; ++nr)
-                                if (!VTTS_EXP_NOMFMA) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
-                                else acc[mr][nr][0] += (float)af[mr][0] * (float)bf[nr][0];
+                                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mr], bf[nr], acc[mr][nr], 0, 0, 0);
 #pragma unroll
                         for (int mr = 0; mr < MR; ++mr) af[mr] = afn[mr];
 #pragma unroll
@@ -280,7 +265,6 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         const int row = u / UPR, c8 = u % UPR;
         const int t = t0 + row;
         if (t >= L) continue;
-        if (VTTS_EXP_NOSTORE && a.slope_out != 12345.f) continue;
         const float4 p0 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8);
         const float4 p1 = *reinterpret_cast<const float4*>(ep + row * EPF + c8 * 8 + 4);
         float v[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
