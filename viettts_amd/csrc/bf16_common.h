@@ -24,7 +24,21 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v >= 0.0f ? v : v * s; }
 // slope 0.1 < 1: leaky_relu(v) = max(v, 0.1 v) — identical values (v >= 0: v >= 0.1 v; v < 0: 0.1 v > v), one op fewer
-__device__ __forceinline__ float lrelu01(float v) { return fmaxf(v, v * 0.1f); }
+// max(a, b) as ONE v_max_f32: fmaxf() makes hipcc canonicalise (v_max_f32 x, x, x) every operand it cannot prove is not a
+// signalling NaN — one extra VALU instruction per element of the staging and epilogue phases, and those share the SIMD's
+// issue port with the co-resident workgroup's MFMAs (profiles/r01_j_kbench_findings.md).  Same value for non-NaN inputs.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float lrelu01(float v) { return vmax_raw(v, v * 0.1f); }
+// LeakyReLU(0.1) of two values rounded to a bf16 pair: one packed multiply, two maxes, one convert
+__device__ __forceinline__ unsigned lrelu01_pack(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    const f32x2 m = v * 0.1f;  // v_pk_mul_f32
+    return pack_bf16x2(vmax_raw(v.x, m.x), vmax_raw(v.y, m.y));
+}
 __device__ __forceinline__ unsigned lrelu_bf16x2(unsigned u, float s) {
     return pack_bf16x2(lrelu_f(bf16_lo(u), s), lrelu_f(bf16_hi(u), s));
 }

@@ -89,27 +89,23 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     VTTS_TL_ID(a, wg_lin);
     VTTS_TL(a, wg_lin, 0);
 
-    // Accumulators start from the bias (row = channel 32*mr + 8*rq + 4*lh + i of this wave's m-block, r = 4*rq + i)
+    // Accumulators start from the bias: the first k-step's MFMAs take a 16-register bias block (row = channel
+    // 32*mr + 8*rq + 4*lh + i of this wave's m-block, r = 4*rq + i; the same for every column block) as their C operand, so
+    // there is no accumulator initialisation at all (it was 128 v_mov per convolution and wave, on the issue port the
+    // co-resident workgroup's MFMAs need).
     f32x16 acc[MR][NR];
-    float4 bq[MR][4];
+    f32x16 bblk[MR];
     auto load_bias = [&](const float* __restrict__ bias) {  // requested a phase ahead of the MFMAs that consume it
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) bq[mr][rq] = *reinterpret_cast<const float4*>(bias + wm * (C / T::WM) + mr * 32 + 8 * rq + 4 * lh);
-    };
-    auto init_acc = [&]() {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    acc[mr][nr][4 * rq + 0] = bq[mr][rq].x;
-                    acc[mr][nr][4 * rq + 1] = bq[mr][rq].y;
-                    acc[mr][nr][4 * rq + 2] = bq[mr][rq].z;
-                    acc[mr][nr][4 * rq + 3] = bq[mr][rq].w;
-                }
+        for (int mr = 0; mr < MR; ++mr) {
+            const float* __restrict__ bp = bias + wm * (C / T::WM) + mr * 32 + 4 * lh;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(bp), q1 = *reinterpret_cast<const f32x4*>(bp + 8);
+            const f32x4 q2 = *reinterpret_cast<const f32x4*>(bp + 16), q3 = *reinterpret_cast<const f32x4*>(bp + 24);
+            const f32x8 lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+            bblk[mr] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        }
     };
     load_bias(a.bias);
 
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         const int nunits = rowsx * SPR1;
         const int tx0 = t0 - H2 - h1;
         const int row0 = tid / SPR1, c = tid % SPR1;
-        auto act2 = [](unsigned u) { return pack_bf16x2(lrelu01(bf16_lo(u)), lrelu01(bf16_hi(u))); };  // LRELU_SLOPE, model.py:5,46
+        auto act2 = [](unsigned u) { return lrelu01_pack(bf16_lo(u), bf16_hi(u)); };  // LRELU_SLOPE, model.py:5,46
         unsigned char* const lds0 = xt + row0 * P1 + ((c ^ swz_of<SPR1>(row0)) << 4);  // unit i: + i * RPI * P1 (same swizzle)
         if (tx0 >= 0 && tx0 + XPT * RPI <= L) {
             // interior tile (all but the first / last of an utterance): no clamping, no masking, constant strides
@@ -183,7 +179,6 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     };
     stage_x(0, std::integral_constant<int, XPT>{});
     VTTS_TL(a, wg_lin, 9);
-    init_acc();
     __syncthreads();  // B1: X tile staged
     VTTS_TL(a, wg_lin, 1);
 
@@ -192,8 +187,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     // A fragment (tap, ks, mr): 16 bytes per lane at  wconv + (((tap*KSTEPS + ks0 + ks)*MB + wm*MR + mr)*64 + lane)*16
     // B fragment (tap, ks, nr): tile row  n + tap*dl  (n = this lane's output column), 16-byte slot 2*ks + lh of that row
     const int rowbase0 = wn * (N1 / WN) + l31;
-    auto conv_phase = [&](const unsigned char* __restrict__ wconv, int dl, auto sprb_tag, auto nks_tag, int ks0) {
+    auto conv_phase = [&](const unsigned char* __restrict__ wconv, int dl, auto sprb_tag, auto nks_tag, int ks0, auto fresh_tag) {
         constexpr int SPRB = decltype(sprb_tag)::value, PB = SPRB * 16, NKS = decltype(nks_tag)::value;
+        constexpr bool FRESH = decltype(fresh_tag)::value;  // the pass's first step starts the accumulators from the bias block
         constexpr int NSTEPS = KS * NKS;
         const uint4* __restrict__ aptr = reinterpret_cast<const uint4*>(wconv) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
         bf16x8 af[RA][MR], bf[2][NR];
@@ -210,12 +206,12 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + row * PB + (((ks * 2 + lh) ^ swz_of<SPRB>(row)) << 4));
             }
         };
-        auto mfma_step = [&](int slot, int par) {
+        auto mfma_step = [&](int slot, int par, bool first) {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][mr], bf[par][nr], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][mr], bf[par][nr], first ? bblk[mr] : acc[mr][nr], 0, 0, 0);
         };
         // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers), and spread
         // them between the MFMAs: grouped issue (all loads, then all MFMAs) left the matrix pipe idle while a lone wave
@@ -245,7 +241,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             for (int s = 0; s < NSTEPS; ++s) {
                 load_a((s + PA) / NKS, (s + PA) % NKS, (s + PA) % RA);
                 if (s + 1 < NSTEPS) load_b((s + 1) / NKS, (s + 1) % NKS, (s + 1) & 1);
-                mfma_step(s % RA, s & 1);
+                mfma_step(s % RA, s & 1, FRESH && s == 0);
                 pin_step(s + 1 < NSTEPS);
             }
         } else {
@@ -253,17 +249,19 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             // of a step depend only on its position in the block
             constexpr int UB = NKS < 8 ? NKS : 8;
             static_assert(T::UNROLL_ALL || (UB % RA == 0 && UB % 2 == 0 && NKS % UB == 0), "ring slot / B parity must be compile-time in the block loop");
-#pragma nounroll
-            for (int s0 = 0; s0 < NSTEPS; s0 += UB) {
+            auto block = [&](int s0, auto first_tag) {  // the first block of a fresh pass is peeled: its first step reads the bias block
 #pragma unroll
                 for (int i = 0; i < UB; ++i) {
                     const int sa = s0 + i + PA, sb = s0 + i + 1;
                     load_a(sa / NKS, sa % NKS, (i + PA) % RA);
                     load_b(sb < NSTEPS ? sb / NKS : KS - 1, sb < NSTEPS ? sb % NKS : 0, (i + 1) & 1);
-                    mfma_step(i % RA, i & 1);
+                    mfma_step(i % RA, i & 1, decltype(first_tag)::value && i == 0);
                     pin_step(true);
                 }
-            }
+            };
+            block(0, std::integral_constant<bool, FRESH>{});
+#pragma nounroll
+            for (int s0 = UB; s0 < NSTEPS; s0 += UB) block(s0, std::false_type{});
         }
     };
 
@@ -275,7 +273,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             stage_x(xc, std::integral_constant<int, 4>{});
             __syncthreads();
         }
-        conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, xc * KSX);
+        if (xc == 0)
+            conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, 0, std::true_type{});
+        else
+            conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, xc * KSX, std::false_type{});
     }
     VTTS_TL(a, wg_lin, 2);
     __syncthreads();  // B2: every wave is done reading the X tile
@@ -303,10 +304,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     const int tt = t0 - H2 + row;
                     const bool ok = tt >= 0 && tt < L;
                     const int r0 = 8 * p;
-                    unsigned p0 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 0]), lrelu01(acc[mr][nr][r0 + 1]));
-                    unsigned p1 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 2]), lrelu01(acc[mr][nr][r0 + 3]));
-                    unsigned q0 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 4]), lrelu01(acc[mr][nr][r0 + 5]));
-                    unsigned q1 = pack_bf16x2(lrelu01(acc[mr][nr][r0 + 6]), lrelu01(acc[mr][nr][r0 + 7]));
+                    unsigned p0 = lrelu01_pack(acc[mr][nr][r0 + 0], acc[mr][nr][r0 + 1]);
+                    unsigned p1 = lrelu01_pack(acc[mr][nr][r0 + 2], acc[mr][nr][r0 + 3]);
+                    unsigned q0 = lrelu01_pack(acc[mr][nr][r0 + 4], acc[mr][nr][r0 + 5]);
+                    unsigned q1 = lrelu01_pack(acc[mr][nr][r0 + 6], acc[mr][nr][r0 + 7]);
                     if (!ok) p0 = p1 = q0 = q1 = 0u;  // c2's own zero padding applies to xt
                     swap_pair(p0, q0);
                     swap_pair(p1, q1);
@@ -321,12 +322,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             *reinterpret_cast<uint4*>(xt + row * P2 + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    init_acc();
     __syncthreads();  // B3: xt tile written
     VTTS_TL(a, wg_lin, 3);
 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
-    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0);
+    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::true_type{});
     VTTS_TL(a, wg_lin, 4);
 
     // ---------------- epilogue 2: + x [MRF accumulate / mean] [consumer's LeakyReLU] -> bf16, 16-byte stores ----------------

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         pd = r[0];
         qd = r[1];
     };
-    auto act2 = [](unsigned u) { return pack_bf16x2(lrelu01(bf16_lo(u)), lrelu01(bf16_hi(u))); };  // LRELU_SLOPE, model.py:5
+    auto act2 = [](unsigned u) { return lrelu01_pack(bf16_lo(u), bf16_hi(u)); };  // LRELU_SLOPE, model.py:5
 
     for (int u = tid; u < 6 * C; u += THREADS) reinterpret_cast<float*>(lds + 2 * T::TILE_BYTES)[u] = a.bias[u];
     // ---- guard rows of both tiles = 0 (never written again) ----
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 for (int p = 0; p < 2; ++p) {
                     const int r0 = 8 * p;
                     const f32x16& c = acc[mr][nr];
-                    write_tile(tT, mr, nr, pack_bf16x2(lrelu01(c[r0 + 0]), lrelu01(c[r0 + 1])), pack_bf16x2(lrelu01(c[r0 + 2]), lrelu01(c[r0 + 3])),
-                               pack_bf16x2(lrelu01(c[r0 + 4]), lrelu01(c[r0 + 5])), pack_bf16x2(lrelu01(c[r0 + 6]), lrelu01(c[r0 + 7])), p);
+                    write_tile(tT, mr, nr, lrelu01_pack(c[r0 + 0], c[r0 + 1]), lrelu01_pack(c[r0 + 2], c[r0 + 3]),
+                               lrelu01_pack(c[r0 + 4], c[r0 + 5]), lrelu01_pack(c[r0 + 6], c[r0 + 7]), p);
                 }
         init_acc(2 * pr + 1);
         __syncthreads();  // T written; every wave is done reading A
