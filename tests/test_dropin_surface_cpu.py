@@ -1,0 +1,48 @@
+"""The reference's import paths and call signatures resolve to this implementation: a user of
+NTT123/vietTTS switches packages, not call sites.  Signatures are checked against the reference's own
+(vietTTS/hifigan/mel2wave.py:20, vietTTS/nat/text2mel.py:22,37,61,85-87, vietTTS/synthesizer.py:12-18)."""
+import importlib
+import inspect
+
+import pytest
+
+
+def test_reference_module_paths_resolve():
+    from vietTTS.hifigan.mel2wave import mel2wave
+    from vietTTS.nat.text2mel import predict_duration, predict_mel, text2mel, text2tokens
+    import viettts_amd.hifigan.mel2wave as m2w
+    import viettts_amd.nat.text2mel as t2m
+
+    assert mel2wave is m2w.mel2wave and text2mel is t2m.text2mel
+    assert list(inspect.signature(mel2wave).parameters) == ["mel"]
+    p = inspect.signature(text2mel).parameters
+    assert list(p) == ["text", "lexicon_fn", "silence_duration"] and p["silence_duration"].default == -1.0
+    assert str(p["lexicon_fn"].default).endswith("lexicon.txt")
+    assert list(inspect.signature(predict_duration).parameters) == ["tokens"]
+    assert list(inspect.signature(predict_mel).parameters)[:2] == ["tokens", "durations"]
+    assert list(inspect.signature(text2tokens).parameters) == ["text", "lexicon_fn"]
+
+
+def test_cli_flags_and_defaults_are_the_references():
+    import vietTTS.synthesizer as syn
+
+    a = syn.build_parser().parse_args(["--text", "xin chào"])
+    assert (str(a.output), a.sample_rate, a.silence_duration, a.lexicon_file) == ("clip.wav", 16000, -1, None)
+    assert syn.nat_normalize_text("Xin  chào, Việt Nam!").startswith("xin chào")
+
+
+def test_out_of_scope_modules_are_absent_not_stubbed():
+    for name in ("vietTTS.nat.trainer", "vietTTS.hifigan.trainer", "vietTTS.nat.data_loader"):
+        with pytest.raises(ImportError):
+            importlib.import_module(name)
+
+
+def test_missing_checkpoints_raise_like_the_reference(tmp_path, monkeypatch):
+    """The reference opens its checkpoint files on every call; without them: FileNotFoundError (no fallback)."""
+    from vietTTS.nat import text2mel as t2m_ref
+    import viettts_amd.nat.text2mel as t2m
+
+    monkeypatch.chdir(tmp_path)
+    t2m.set_duration_model(None)
+    with pytest.raises((FileNotFoundError, OSError)):
+        t2m_ref.predict_duration([1, 2, 3])
