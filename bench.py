@@ -106,10 +106,11 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
     if own:
         gen = Generator(V1, device="cuda:0", dtype="bf16")
         gen.load_params(synthetic_params(V1, 4321, "scaled"))
-    dm = DurationModel(device=str(gen.device))
-    dm.load_params(*synthetic_duration_checkpoint())
-    am = AcousticModel(device=str(gen.device))
-    am.load_params(*synthetic_acoustic_checkpoint())
+    from viettts_amd import dist as vdist
+
+    # rank 0 loads and packs each checkpoint, the other ranks receive the packed blobs: one broadcast per model
+    dm = vdist.setup_model_dp(DurationModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_duration_checkpoint()))
+    am = vdist.setup_model_dp(AcousticModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_acoustic_checkpoint()))
     sents = synthetic_sentences(n)
     out = {}
     for _ in range(2):  # the first pass warms allocators and code objects

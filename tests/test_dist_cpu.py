@@ -76,6 +76,28 @@ def _worker(rank, world, port, q):
         ok_gather = all(torch.equal(got[r], torch.cat([torch.full((lengths[i],), float(i)) for i in plan[r]])) for r in range(world))
     else:
         ok_gather = got is None
+    # the start-up protocol itself (viettts_amd.dist.setup_model_dp) on a stand-in model: rank 0 loads and packs, rank 1
+    # must never call load_params and ends up with rank 0's bytes
+    class FakeModel:
+        device = torch.device("cpu")
+        packed_bytes = 4096
+
+        def __init__(self):
+            self._blob, self.loaded, self.adopted = None, False, False
+
+        def load_params(self, seed):
+            self.loaded = True
+            self._blob = (torch.arange(4096, dtype=torch.int64) * seed % 253).to(torch.uint8)
+
+        def packed_blob(self):
+            return self._blob
+
+        def adopt_packed(self, blob):
+            self.adopted, self._blob = True, blob
+
+    m = vdist.setup_model_dp(FakeModel(), lambda mm: mm.load_params(7 + rank), info)  # a rank-dependent seed: only rank 0's may win
+    want = (torch.arange(4096, dtype=torch.int64) * 7 % 253).to(torch.uint8)
+    ok_bcast = ok_bcast and bool(torch.equal(m._blob, want)) and m.loaded == (rank == 0) and m.adopted == (rank != 0)
     q.put((rank, ok_bcast, ok_gather))
     dist.barrier()
     dist.destroy_process_group()

@@ -240,3 +240,28 @@ def test_acoustic_wide_batch_rows_equal_rows_alone(acoustic):
     masks = no.threefry_keep_masks(seeds[40], nf, 256)
     ref = no.acoustic_inference(P, S, np.array(tok), dur, nf, prenet_masks=lambda f: (masks[f, 0], masks[f, 1]))
     assert np.abs(got[40] - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_nat_models_run_from_an_adopted_blob(model, acoustic):
+    """The data-parallel start-up (viettts_amd.dist.setup_model_dp): a rank that never saw the checkpoint binds the
+    packed blob rank 0 broadcast and computes the same durations and mel bit for bit."""
+    from viettts_amd.nat.acoustic import AcousticModel
+    from viettts_amd.nat.duration import DurationModel
+
+    dm, _, _ = model
+    am, _, _ = acoustic
+    dm2, am2 = DurationModel(device="cuda:0"), AcousticModel(device="cuda:0")
+    try:
+        assert dm2.packed_bytes == dm.packed_blob().numel() and am2.packed_bytes == am.packed_blob().numel()
+        dm2.adopt_packed(dm.packed_blob().clone())
+        am2.adopt_packed(am.packed_blob().clone())
+        sents = [[3, 9, 27, 5], [8, 1, 4, 4, 60, 2, 11]]
+        for a, b in zip(dm(sents), dm2(sents)):
+            assert np.array_equal(a, b)
+        tok, dur, nf = _case(61, 12)
+        assert np.array_equal(am([tok], [dur], [nf], dropout_seeds=[5])[0], am2([tok], [dur], [nf], dropout_seeds=[5])[0])
+        with pytest.raises(ValueError):
+            am2.adopt_packed(torch.zeros(16, dtype=torch.uint8, device="cuda:0"))
+    finally:
+        dm2.close()
+        am2.close()

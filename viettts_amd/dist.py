@@ -114,20 +114,27 @@ def broadcast_packed_weights(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     return blob
 
 
-def setup_generator_dp(gen, params_fn, info: Optional[RankInfo] = None):
-    """Rank 0 builds/loads + packs the weights, every other rank receives the packed blob.
-    ``params_fn()`` returns the Haiku parameter dict and is only called on rank 0."""
+def setup_model_dp(model, load_fn, info: Optional[RankInfo] = None):
+    """Rank 0 loads + packs the weights (``load_fn(model)`` calls its ``load_params`` and runs on rank 0 only), every other
+    rank receives the packed blob: ONE broadcast per model at start-up (HiFi-GAN generator 27.9 MB bf16 / 55.7 MB fp32,
+    NAT duration model, NAT acoustic model).  ``model`` offers ``packed_bytes``, ``packed_blob()``, ``adopt_packed(blob)``
+    and ``device`` (Generator, DurationModel, AcousticModel)."""
     info = info or rank_info()
     if info.world == 1 or info.rank == 0:
-        gen.load_params(params_fn())
-        blob = gen.packed_blob()
+        load_fn(model)
+        blob = model.packed_blob()
     else:
-        blob = torch.empty(gen.packed_bytes, dtype=torch.uint8, device=gen.device)
+        blob = torch.empty(model.packed_bytes, dtype=torch.uint8, device=model.device)
     if info.world > 1:
         broadcast_packed_weights(blob, 0)
         if info.rank != 0:
-            gen.adopt_packed(blob)
-    return gen
+            model.adopt_packed(blob)
+    return model
+
+
+def setup_generator_dp(gen, params_fn, info: Optional[RankInfo] = None):
+    """:func:`setup_model_dp` for the generator: ``params_fn()`` returns the Haiku parameter dict (rank 0 only)."""
+    return setup_model_dp(gen, lambda g: g.load_params(params_fn()), info)
 
 
 def gather_to_rank0(local: torch.Tensor, info: Optional[RankInfo] = None) -> Optional[List[torch.Tensor]]:

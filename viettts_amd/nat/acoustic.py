@@ -67,6 +67,25 @@ class AcousticModel:
             out.append((mod.value.decode(), name.value.decode(), tuple(int(shape[d]) for d in range(nd.value))))
         return out
 
+    # ---- packed weights: rank 0 packs, the other ranks of a data-parallel job receive the blob (viettts_amd/dist.py) ----
+    @property
+    def packed_bytes(self) -> int:
+        n = C.c_size_t(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_packed_bytes(self._h, C.byref(n)))
+        return int(n.value)
+
+    def packed_blob(self) -> torch.Tensor:
+        if self._blob is None:
+            raise RuntimeError("no parameters loaded")
+        return self._blob
+
+    def adopt_packed(self, blob: torch.Tensor) -> None:
+        """Bind a packed blob produced by another rank's ``load_params`` (one broadcast at start-up, no data-path collective)."""
+        if blob.dtype != torch.uint8 or blob.numel() < self.packed_bytes or blob.device != self.device:
+            raise ValueError("packed blob must be a uint8 tensor of packed_bytes on this model's device")
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_bind_packed(self._h, _ptr(blob), blob.numel()))
+        self._blob = blob
+
     def load_params(self, params: HaikuDict, state: HaikuDict) -> None:
         """``dic["params"]`` and ``dic["aux"]`` of acoustic_latest_ckpt.pickle (text2mel.py:62-71)."""
         for mod, name, shape in self.param_table():
