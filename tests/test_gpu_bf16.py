@@ -242,3 +242,28 @@ def test_ragged_batch_equals_each_utterance_alone(fuse):
             assert not got[b, 256 * n :].any()
     finally:
         gen.close()
+
+
+def test_ragged_batch_across_micro_batches_and_streams():
+    """The engine splits a large batch into micro-batches (optionally on several streams); every micro-batch must see ITS
+    utterances' lengths."""
+    from viettts_amd.hifigan.generator import Generator
+
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    try:
+        rng = np.random.default_rng(5)
+        frames = [int(v) for v in rng.integers(3, 97, size=37)]
+        T = max(frames)
+        g = torch.Generator().manual_seed(7)
+        mel = torch.clamp(-5 + 2 * torch.randn(len(frames), T, 80, generator=g), -11.5129, 2.0).to("cuda:0")
+        want = {b: gen(mel[b : b + 1, : frames[b]].contiguous()).cpu().numpy()[0] for b in (0, 9, 16, 17, 31, 36)}
+        for mb, streams in ((0, 1), (8, 1), (16, 2)):
+            gen.set_option("microbatch", mb)
+            gen.set_option("streams", streams)
+            got = gen.forward_ragged(mel, frames).cpu().numpy()
+            for b, w in want.items():
+                assert np.array_equal(got[b, : 256 * frames[b]], w), (mb, streams, b)
+                assert not got[b, 256 * frames[b] :].any()
+    finally:
+        gen.close()
