@@ -199,8 +199,16 @@ def main():
     # ---- text -> waveform (BASELINE configs[3]): 256 sentences sharded over the ranks; whole job = max over ranks ----
     pipe = None
     if not args.no_rtf and args.dtype == "bf16":
-        pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier)
-        if n_gpus > 1:
+        try:
+            pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier)
+        except Exception as e:  # a side measurement must not take the headline line down with it
+            pipe = {"error": f"{type(e).__name__}: {e}"}
+        if n_gpus > 1:  # the ranks agree on whether to combine (a failed rank would otherwise leave the others in a collective)
+            ok = torch.tensor([0.0 if "error" in pipe else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() < 1.0 and "error" not in pipe:
+                pipe = {"error": "another rank failed"}
+        if n_gpus > 1 and "error" not in pipe:
             keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "generator_ms", "total_ms", "frames_max"]
             keys_sum = ["tokens", "frames", "samples"]
             tmax = torch.tensor([float(pipe[k]) for k in keys_max], dtype=torch.float64, device=dev)
@@ -211,8 +219,9 @@ def main():
                 pipe[k] = v
             for k, v in zip(keys_sum, tsum.tolist()):
                 pipe[k] = int(v)
-        pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
-        pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
+        if "error" not in pipe:
+            pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
+            pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
 
     assert bool(torch.isfinite(out[0, :4096]).all()), "non-finite output"
 
