@@ -524,8 +524,11 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
 //                                                               keep[b][f][0|1][PN] bytes (1 = keep, value * 2), nullptr = none
 //   x = [cond_f ; p];  h1 = LSTM1([x ; h1]);  h2 = LSTM2([[h1 ; x] ; h2])      hk.deep_rnn_with_skip_connections
 //   mel_f = [h1 ; h2] @ wp + bp;  prev = mel_f
-// Decoder state in HBM, k-major with the sentences contiguous (Bp = B rounded up to 32 columns), ping-pong by frame parity:
-//   Z[parity][row][Bp], rows [ h1 (H) | cond_f (E) | p (PN) | h2 (H) ]:  LSTM1 reads rows [H, H+E+PN) of the current
+// Decoder state in HBM, k-major in groups of four rows with the sentences contiguous (Bp = B rounded up to 64 columns),
+// ping-pong by frame parity:
+//   Z[parity][row / 4][Bp][row % 4]  (one 16-byte load per lane = 4 consecutive rows of its sentence: the LSTM step is bound
+//   by the number of vector-memory instructions a CU can issue, and dword loads of the state were 8 of its 9 per iteration),
+//   rows [ h1 (H) | cond_f (E) | p (PN) | h2 (H) ]:  LSTM1 reads rows [H, H+E+PN) of the current
 //   parity then h1 of the previous one; LSTM2 reads rows [0, H+E+PN) of the current parity then h2 of the previous one —
 //   exactly the row order of the two Haiku weight matrices.  Cell states c1, c2 as [H][Bp].
 //
@@ -533,9 +536,10 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
 // M = the slice's 32 gate columns ordered 4*unit + gate, N = 32 sentences, K = 2 per instruction).  With that row order a
 // lane's 16 accumulators are the i, g, f, o pre-activations of 4 (unit, sentence) pairs: the LSTM cell update
 // (hk.LSTM: gates i, g, f, o; forget bias +1) happens in registers, no exchange.  Weights host-packed per slice so that one
-// 16-byte load per lane feeds 4 MFMAs ([slice][K/8][lane][4]: element i = W[8*kb + 2*i + lane/32][col(lane%32)]);
+// 16-byte load per lane feeds 4 MFMAs ([slice][K/8][lane][4]: element i = W[8*kb + 4*(lane/32) + i][col(lane%32)]);
 // activations straight from Z (128-byte rows, L2-resident); both PD iterations (8 k each) ahead in registers.
 // Every output element depends on its own sentence's column only: rows are bit-identical alone or batched.
+__device__ __forceinline__ size_t nat_zidx(int row, int b, int Bp) { return ((size_t)(row >> 2) * Bp + b) * 4 + (row & 3); }
 constexpr int NAT_DEC_PD = 4;   // iterations (8 k each) a wave keeps in flight (7 measured no faster: the step is L2-bandwidth-bound)
 
 // NT = 32-sentence tiles per wave (one weight fragment feeds NT MFMAs: L2 traffic for the weights / NT), KW = waves per
@@ -573,17 +577,16 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restric
             }
         }
     float4 wv[NAT_DEC_PD];
-    float xv[NAT_DEC_PD][NT][4];
+    float4 xv[NAT_DEC_PD][NT];
     const float4* __restrict__ wsl = wpk + (size_t)slice * NIT * 64 + lane;
     auto load_it = [&](int it, int slot) {
         if (it >= NIT) it = NIT - 1;  // tail: an in-bounds re-read, never used
         wv[slot] = wsl[(size_t)it * 64];
         const int k0 = it * 8;
-        const float* __restrict__ xr = (k0 < KA ? inA + (size_t)k0 * Bp : inB + (size_t)(k0 - KA) * Bp) + (size_t)lh * Bp + b0 + l31;
+        // rows k0 + 4*lh .. + 3 of this lane's sentences: MFMA j of the iteration takes k = k0 + 4*(lane/32) + j on both operands
+        const float* __restrict__ xr = (k0 < KA ? inA + (size_t)k0 * Bp : inB + (size_t)(k0 - KA) * Bp) + ((size_t)lh * Bp + b0 + l31) * 4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xv[slot][nt][i] = xr[(size_t)(2 * i) * Bp + 32 * nt];
+        for (int nt = 0; nt < NT; ++nt) xv[slot][nt] = *reinterpret_cast<const float4*>(xr + (size_t)(32 * nt) * 4);
     };
 #pragma unroll
     for (int j = 0; j < NAT_DEC_PD; ++j) load_it(it_lo + j, j);
@@ -593,13 +596,13 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restric
         for (int j = 0; j < NAT_DEC_PD; ++j) {
             if (it0 + j >= NW) break;  // wave-uniform
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, xv[j][nt][0], acc[nt][0], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, xv[j][nt].x, acc[nt][0], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, xv[j][nt][1], acc[nt][1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, xv[j][nt].y, acc[nt][1], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].z, xv[j][nt][2], acc[nt][0], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].z, xv[j][nt].z, acc[nt][0], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].w, xv[j][nt][3], acc[nt][1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].w, xv[j][nt].w, acc[nt][1], 0, 0, 0);
             const int nx = it0 + j + NAT_DEC_PD;
             load_it(nx < NW ? it_lo + nx : NIT, j);
         }
@@ -638,7 +641,7 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restric
             float c = cst[(size_t)u * Bp + b];
             c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
             cst[(size_t)u * Bp + b] = c;
-            hout[(size_t)u * Bp + b] = sigmoidf_(go) * tanhf(c);
+            hout[nat_zidx(u, b, Bp)] = sigmoidf_(go) * tanhf(c);
         }
     }
 }
@@ -684,7 +687,7 @@ __global__ void nat_keep_masks_k(const unsigned long long* __restrict__ seeds, u
 // Frame 0's input: h1 = h2 = 0, c = 0 (memset), prenet(0) = 0 (no biases), cond_0 from the upsampler.
 __global__ void nat_dec_init_k(const float* __restrict__ cond, float* __restrict__ zcond, int B, int Bp, int Fmax, int E) {
     const int b = blockIdx.x;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) zcond[(size_t)e * Bp + b] = cond[(size_t)b * Fmax * E + e];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) zcond[nat_zidx(e, b, Bp)] = cond[(size_t)b * Fmax * E + e];
 }
 
 // mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 and its cond row into the other parity's state.  One
@@ -710,7 +713,10 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     }
     if (!any) return;
     const int X = E + PN;
-    for (int k = g; k < 2 * H; k += 1024) hs[k] = *reinterpret_cast<const float4*>(zcur + (size_t)(k < H ? k : k + X) * Bp + b0);
+    for (int k = g; k < 2 * H; k += 1024) {
+        const float* __restrict__ zr = zcur + nat_zidx(k < H ? k : k + X, b0, Bp);  // the 4 sentences of this row: 16 bytes apart
+        hs[k] = make_float4(zr[0], zr[4], zr[8], zr[12]);
+    }
     __syncthreads();
     // out[col] (4 sentences) = sum over chunk `ch` of rows [ch*per, (ch+1)*per) of src[row] * w[row][col]
     auto partial = [&](const float4* __restrict__ src, const float* __restrict__ w, int rows, int width, int col, int ch, int per) {
@@ -760,14 +766,20 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         float v[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) v[s] = b0 + s < B ? cond[((size_t)(b0 + s) * Fmax + f + 1) * E + e] : 0.0f;
-        *reinterpret_cast<float4*>(znext + (size_t)(H + e) * Bp + b0) = make_float4(v[0], v[1], v[2], v[3]);
+        float* __restrict__ zw = znext + nat_zidx(H + e, b0, Bp);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zw[4 * s] = v[s];
     }
     __syncthreads();
     if (g < PN) p1[g] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 0, g);
     __syncthreads();
     if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, (PN + nchN - 1) / nchN);
     __syncthreads();
-    if (g < PN) *reinterpret_cast<float4*>(znext + (size_t)(H + E + g) * Bp + b0) = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
+    if (g < PN) {
+        const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
+        float* __restrict__ zw = znext + nat_zidx(H + E + g, b0, Bp);
+        zw[0] = r.x; zw[4] = r.y; zw[8] = r.z; zw[12] = r.w;
+    }
 }
 
 // ---- shared host-side sequence: TokenEncoder of `m` under module prefix `te` -> enc [B][Lmax][2D] ------------------
@@ -925,7 +937,7 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
         });
     }
     // decoder LSTM weights in MFMA A-fragment order (nat_dec_lstm_k): [slice = 8 units][K/8][lane][4],
-    // element i of lane = W[8*kb + 2*i + lane/32][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
+    // element i of lane = W[8*kb + 4*(lane/32) + i][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
     for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
         const std::string mod = l;
         const int K = mod == "lstm/linear" ? X + H : H + X + H;
@@ -936,7 +948,7 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
                 for (int kb = 0; kb < NIT; ++kb)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
-                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)(8 * kb + 2 * i + lh) * 4 * H + col];
+                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)(8 * kb + 4 * lh + i) * 4 * H + col];
                     }
         });
     }
