@@ -694,8 +694,8 @@ __global__ void nat_dec_init_k(const float* __restrict__ cond, float* __restrict
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
 __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext, const float* __restrict__ cond,
-                                                              const int* __restrict__ nframes, const float* __restrict__ f1, const float* __restrict__ f2,
-                                                              const float* __restrict__ wp, const float* __restrict__ bp,
+                                                              const int* __restrict__ nframes, const float4* __restrict__ f1, const float4* __restrict__ f2,
+                                                              const float4* __restrict__ wp, const float* __restrict__ bp,
                                                               const unsigned char* __restrict__ keep, float* __restrict__ mel, int f, int B, int Bp,
                                                               int Fmax, int E, int PN, int H, int MEL) {
     extern __shared__ float4 sq[];
@@ -719,14 +719,20 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     }
     __syncthreads();
     // out[col] (4 sentences) = sum over chunk `ch` of rows [ch*per, (ch+1)*per) of src[row] * w[row][col]
-    auto partial = [&](const float4* __restrict__ src, const float* __restrict__ w, int rows, int width, int col, int ch, int per) {
+    // weights in [row / 4][col][4] order (pack-time copies "…#k4"): one 16-byte load per lane = 4 consecutive rows of its
+    // column, a wave's loads 1 KiB contiguous — dword loads made the step wait on the number of vector-memory instructions
+    // a CU can issue (2 700 per workgroup and frame)
+    auto partial = [&](const float4* __restrict__ src, const float4* __restrict__ w4, int rows, int width, int col, int ch, int per) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;
-#pragma unroll 8
-        for (int k = ch * per; k < k1; ++k) {
-            const float wv = w[(size_t)k * width + col];
-            const float4 x = src[k];
-            a.x = fmaf(x.x, wv, a.x); a.y = fmaf(x.y, wv, a.y); a.z = fmaf(x.z, wv, a.z); a.w = fmaf(x.w, wv, a.w);
+        const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;  // per and rows are multiples of 4
+#pragma unroll 4
+        for (int k = ch * per; k < k1; k += 4) {
+            const float4 wv = w4[(size_t)(k >> 2) * width + col];
+            const float4 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
+            a.x = fmaf(x0.x, wv.x, a.x); a.y = fmaf(x0.y, wv.x, a.y); a.z = fmaf(x0.z, wv.x, a.z); a.w = fmaf(x0.w, wv.x, a.w);
+            a.x = fmaf(x1.x, wv.y, a.x); a.y = fmaf(x1.y, wv.y, a.y); a.z = fmaf(x1.z, wv.y, a.z); a.w = fmaf(x1.w, wv.y, a.w);
+            a.x = fmaf(x2.x, wv.z, a.x); a.y = fmaf(x2.y, wv.z, a.y); a.z = fmaf(x2.z, wv.z, a.z); a.w = fmaf(x2.w, wv.z, a.w);
+            a.x = fmaf(x3.x, wv.w, a.x); a.y = fmaf(x3.y, wv.w, a.y); a.z = fmaf(x3.z, wv.w, a.z); a.w = fmaf(x3.w, wv.w, a.w);
         }
         return a;
     };
@@ -737,7 +743,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         }
         return a;
     };
-    const int nchP = 1024 / MEL, perP = (2 * H + nchP - 1) / nchP;
+    const int nchP = 1024 / MEL, perP = ((2 * H + nchP - 1) / nchP + 3) / 4 * 4;
     if (g < nchP * MEL) part[g] = partial(hs, wp, 2 * H, MEL, g % MEL, g / MEL, perP);
     __syncthreads();
     if (g < MEL) {
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         return make_float4(v[0], v[1], v[2], v[3]);
     };
     const int nchN = 1024 / PN;
-    if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, (MEL + nchN - 1) / nchN);
+    if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, ((MEL + nchN - 1) / nchN + 3) / 4 * 4);
     for (int e = g; e < E; e += 1024) {  // cond_{f+1} of the 4 sentences
         float v[4];
 #pragma unroll
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     __syncthreads();
     if (g < PN) p1[g] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 0, g);
     __syncthreads();
-    if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, (PN + nchN - 1) / nchN);
+    if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, ((PN + nchN - 1) / nchN + 3) / 4 * 4);
     __syncthreads();
     if (g < PN) {
         const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
@@ -936,6 +942,16 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
                             }
         });
     }
+    // projection and prenet matrices in [row / 4][col][4] order (nat_dec_proj_prenet_k: one 16-byte load = 4 rows of a column)
+    for (const char* l : {"linear", "linear_1", "linear_2"}) {
+        const std::string mod = l;
+        const int rows = mod == "linear" ? 2 * H : (mod == "linear_1" ? MEL : PN), cols = mod == "linear" ? MEL : PN;
+        h->add_extra(mod + "#k4", (size_t)rows * cols * sizeof(float), [mod, rows, cols](const NatModel& m, float* out) {
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            for (int k = 0; k < rows; ++k)
+                for (int c = 0; c < cols; ++c) out[((size_t)(k >> 2) * cols + c) * 4 + (k & 3)] = W[(size_t)k * cols + c];
+        });
+    }
     // decoder LSTM weights in MFMA A-fragment order (nat_dec_lstm_k): [slice = 8 units][K/8][lane][4],
     // element i of lane = W[8*kb + 4*(lane/32) + i][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
     for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
@@ -1052,7 +1068,10 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
         const float4* w1 = reinterpret_cast<const float4*>(h->extra("lstm/linear#mfma"));
         const float4* w2 = reinterpret_cast<const float4*>(h->extra("lstm_1/linear#mfma"));
         const float *b1 = h->dev("lstm/linear", "b"), *b2 = h->dev("lstm_1/linear", "b");
-        const float *f1 = h->dev("linear_1", "w"), *f2 = h->dev("linear_2", "w"), *wp = h->dev("linear", "w"), *bp = h->dev("linear", "b");
+        const float4* f1 = reinterpret_cast<const float4*>(h->extra("linear_1#k4"));
+        const float4* f2 = reinterpret_cast<const float4*>(h->extra("linear_2#k4"));
+        const float4* wp = reinterpret_cast<const float4*>(h->extra("linear#k4"));
+        const float* bp = h->dev("linear", "b");
         const bool wide = B > 32;  // two 32-sentence tiles per wave once there are that many sentences
         const dim3 lgrid(H / 8, wide ? Bp / 64 : 1);
         auto lstm = [&](const float* inA, int KA, const float* inB, const float4* w, const float* bias, float* cst, float* hout, int f) {
