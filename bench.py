@@ -150,14 +150,17 @@ def main():
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
 
-    info = vdist.init_process_group()
+    # VTTS_DIST_BACKEND=gloo + VTTS_SHARE_GPU=1: a dry run of the N > 1 code path on a ONE-GPU box (every rank on cuda:0,
+    # collectives staged through the host) — a development check, never a measurement
+    info = vdist.init_process_group(os.environ.get("VTTS_DIST_BACKEND") or None)
     if info.world != args.gpus:
         if info.rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}; using WORLD_SIZE", file=sys.stderr)
     n_gpus = info.world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(info.local_rank)
-    dev = torch.device("cuda", info.local_rank)
+    dev_index = 0 if os.environ.get("VTTS_SHARE_GPU") else info.local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     gen = Generator(V1, device=dev, dtype=args.dtype)
     if args.microbatch:
@@ -216,7 +219,7 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             for k, v in zip(keys_max, tmax.tolist()):
-                pipe[k] = v
+                pipe[k] = int(v) if k == "frames_max" else v
             for k, v in zip(keys_sum, tsum.tolist()):
                 pipe[k] = int(v)
         if "error" not in pipe:
