@@ -16,8 +16,13 @@
 //   * LDS holds only the activation tile (<= 78 KiB), so two 4-wave workgroups share a CU; nothing couples their phases.
 //     C = 256: 128-column tiles, the X tile staged 128 input channels at a time (2 x 45 KiB), the xt tile 69 KiB.
 // s_barrier remains at the three tile-level hand-offs (X staged / X dead / xt written).
-// Tried and measured no better (tools/kbench, round 1): 32 x 128 wave tiles with three workgroups per CU (LDS read traffic per
-// MFMA doubles), a 7-deep weight ring, 8-wave workgroups, a forced start offset between a CU's two workgroups (0 .. 100k cycles).
+// Tried and measured no better (tools/kbench, round 1; profiles/r01_e_*, r01_j_kbench_findings.md): 32 x 128 wave tiles with
+// three workgroups per CU (LDS read traffic per MFMA doubles), a 7-deep weight ring, 8-wave workgroups, a forced start offset
+// between a CU's two workgroups (they drift to anti-phase by themselves), random start delays that desynchronise the CUs,
+// s_setprio in the loops or in the staging / epilogue phases, a channel-blocked global layout for the epilogue's accesses
+// (emulated: +1.5 %), the raw residual rows kept in LDS at C = 32 (-29 % HBM bytes, 0.8 % slower).  What did help late in the
+// round: one look-ahead load after each MFMA instead of grouped issue (+2.1 %), LeakyReLU as packed multiply + raw v_max
+// and the bias block as the first MFMA's C operand (-30 % VALU instructions per tile, +0.7 %).
 #include <stdio.h>
 #include <string.h>
 
