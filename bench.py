@@ -11,7 +11,13 @@ no data-path collective.  Rank 0 prints ONE JSON line with:
   value        whole-job audio samples/sec (all N GPUs), inputs resident in HBM
   rtf_b1       latency / RTF of a single 512-frame utterance (BASELINE configs[1]), rank 0
   roofline     dominant ResBlock-conv kernel: algorithmic FLOPs / HIP-event time, vs the MFMA peak
-  cpu_baseline the oracle (numpy restatement of the reference) timed on this box's host cores
+  parity_bf16  max-abs / SNR of the bf16 engine against the reference generator's fp64 output (tests/golden)
+  cpu_baseline the REFERENCE's own torch generator (oracle/_ref, built by oracle/build_ref.py) on this box's host cores;
+               the numpy port of the oracle when that archive is absent (kind says which)
+
+With ``--gpus N`` (N > 1) and no WORLD_SIZE in the environment the script re-executes itself under
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``: one rank per GPU, backend
+"nccl" (= RCCL), exactly the launch the driver uses.
 """
 from __future__ import annotations
 
@@ -39,9 +45,71 @@ FLOP_PER_SAMPLE = 2398848  # 2 x MAC of all convolutions per out
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: dense MFMA peaks
 
 
+def _host_threads() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline_reference(budget_s: float = 25.0):
+    """the reference's own PyTorch generator (vietTTS/hifigan/torch_model.py:156-218, weight norm removed)
+    on ALL host cores, fp32 — compiled to a TorchScript archive by oracle/build_ref.py where /root/reference exists and
+    carried to this box under oracle/_ref/.  Same synthetic weights (W_scaled seed 4321) and mels (seed 1234) as the GPU
+    run.  B=1 x T=512: 1 warm-up + median of 5 (RTF); B=4 x T=1024: median of 2 (throughput) while the time budget lasts.
+    Returns None when the archive is absent."""
+    path = os.path.join(REPO, "oracle", "_ref", "torch_generator_v1.pt")
+    if not os.path.exists(path):
+        return None
+    from viettts_amd.hifigan.weights import haiku_to_state_dict
+
+    cores = _host_threads()
+    torch.set_num_threads(cores)
+    ts = torch.jit.load(path, map_location="cpu").eval()
+    sd = {k: torch.from_numpy(v) for k, v in haiku_to_state_dict(V1, synthetic_params(V1, 4321, "scaled")).items()}
+    ts.load_state_dict(sd, strict=True)
+    t_begin = time.perf_counter()
+
+    def run(B, T, reps, warm):
+        x = torch.from_numpy(synthetic_mel(B, T, 1234)).permute(0, 2, 1).contiguous()
+        times = []
+        with torch.no_grad():
+            for i in range(warm + reps):
+                t0 = time.perf_counter()
+                y = ts(x)
+                dt = time.perf_counter() - t0
+                if i >= warm:
+                    times.append(dt)
+                if time.perf_counter() - t_begin > budget_s and times:
+                    break
+        assert y.shape == (B, 1, 256 * T) and bool(torch.isfinite(y).all())
+        return statistics.median(times), len(times)
+
+    med1, n1 = run(1, 512, 5, 1)
+    out = {
+        "value": 256 * 512 / med1,
+        "unit": "samples/s",
+        "cores": int(cores),
+        "kind": "reference",
+        "impl": "reference-torch: vietTTS/hifigan/torch_model.py::Generator (TorchScript archive oracle/_ref/torch_generator_v1.pt), "
+                "fp32, torch CPU threads = cores; the reference's JAX-CPU path is not installable offline (no jax/jaxlib/haiku)",
+        "sample": f"B=1 x T=512 frames (131072 samples), 1 warm-up + median of {n1}",
+        "ms": med1 * 1e3,
+        "rtf_16000": med1 / (131072 / 16000.0),
+        "rtf_22050": med1 / (131072 / 22050.0),
+    }
+    if time.perf_counter() - t_begin < budget_s * 0.5:
+        med4, n4 = run(4, 1024, 2, 0)
+        out["b4_T1024"] = {"samples_per_s": 4 * 256 * 1024 / med4, "ms": med4 * 1e3, "reps": n4}
+    return out
+
+
 def cpu_baseline(reps: int = 3, T: int = 512):
-    """The oracle (CPU restatement of the reference generator, fp32, BLAS-threaded) on the host
-    cores.  Bounded sample: `reps` single utterances of T frames.  Baseline only."""
+    """The reference's torch generator when its archive travelled here (kind "reference"); else the oracle (CPU restatement
+    of the reference generator, fp32, BLAS-threaded) as a labelled port.  Bounded sample.  Baseline only."""
+    ref = cpu_baseline_reference()
+    if ref is not None:
+        return ref
     from oracle.hifigan_oracle import generator_forward
 
     try:
@@ -64,9 +132,40 @@ def cpu_baseline(reps: int = 3, T: int = 512):
         "unit": "samples/s",
         "cores": int(cores),
         "kind": "port",
-        "sample": f"oracle/hifigan_oracle.py fp32 (numpy+BLAS restatement of the reference generator), B=1 x T={T} frames, median of {reps}",
+        "sample": f"oracle/hifigan_oracle.py fp32 (numpy+BLAS restatement of the reference generator; oracle/_ref archive absent), B=1 x T={T} frames, median of {reps}",
         "ms": med * 1e3,
     }
+
+
+def parity_bf16(gen, dev):
+    """The bf16 engine against the reference generator's fp64 output (tests/golden, minted by oracle/make_golden.py from the
+    reference's torch generator): B=1 x T=512 and rows 0, 37, 63 of THIS benchmark's batch (64 x 1024).  Strided samples."""
+    out = {}
+    gdir = os.path.join(REPO, "tests", "golden")
+    try:
+        with open(os.path.join(gdir, "golden_meta.json")) as f:
+            meta = json.load(f)["cases"]
+        for case, B, T in (("v1_scaled_T512", 1, 512), ("v1_scaled_B64_T1024", 64, 1024)):
+            rec, g = meta[case], np.load(os.path.join(gdir, case + ".npz"))
+            rows = rec.get("rows", list(range(B)))
+            mel = torch.from_numpy(synthetic_mel(B, T, rec["mseed"])).to(dev)
+            wav, pre = gen.forward_tap(mel, "pre_tanh")
+            torch.cuda.synchronize()
+            idx = torch.from_numpy(g["idx"]).to(dev)
+            y = wav[rows][:, idx].double().cpu().numpy()
+            p = pre[rows][:, idx].double().cpu().numpy()
+            out[f"B{B}xT{T}"] = {
+                "max_abs_wav": float(np.abs(y - g["y64"]).max()),
+                "max_abs_pre_tanh": float(np.abs(p - g["pre64"]).max()),
+                "snr_db_pre_tanh": float(10 * np.log10((g["pre64"] ** 2).mean() / ((p - g["pre64"]) ** 2).mean())),
+                "rows": rows, "samples_compared": int(y.size),
+            }
+            del wav, pre, mel
+        out["reference"] = "fp64 output of vietTTS/hifigan/torch_model.py::Generator on the same seeded weights and mels"
+        out["tolerance"] = "north_star fixes 1e-4 for fp32 only (fp32_path below); bf16 bound asserted in tests: max-abs < 0.03, SNR > 38 dB"
+    except Exception as e:  # a side report must not take the headline down
+        out = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def pmc_traffic(kernel: str, args, B: int, T: int):
@@ -86,7 +185,8 @@ def pmc_traffic(kernel: str, args, B: int, T: int):
 
 
 def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
-    """BASELINE.json configs[3]: n synthetic sentences (synthetic checkpoints; token statistics of lexicon output) -> NAT
+    """BASELINE.json configs[3]: n sentences cycled from the reference's demo transcript x the InfoRe lexicon (SURVEY.md §8d;
+    fixtures tests/golden/text/, token ids pinned to the reference's own text2tokens) with synthetic checkpoints -> NAT
     duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) -> HiFi-GAN bf16 in
     ragged batches; this rank's shard of the sentences (viettts_amd.dist.shard_utterances; no exchange step).  Second pass
     timed, device-synchronised per stage, host work included.  Returns this rank's numbers; main() combines the ranks."""
@@ -99,7 +199,7 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
     from viettts_amd.hifigan.synth import synthetic_params
     from viettts_amd.nat.acoustic import AcousticModel
     from viettts_amd.nat.duration import DurationModel
-    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint, synthetic_duration_checkpoint, synthetic_sentences
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint, synthetic_duration_checkpoint, transcript_sentences
     from viettts_amd.pipeline import synthesize_sentences
 
     own = gen is None
@@ -111,7 +211,8 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
     # rank 0 loads and packs each checkpoint, the other ranks receive the packed blobs: one broadcast per model
     dm = vdist.setup_model_dp(DurationModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_duration_checkpoint()))
     am = vdist.setup_model_dp(AcousticModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_acoustic_checkpoint()))
-    sents = synthetic_sentences(n)
+    tdir = os.path.join(REPO, "tests", "golden", "text")
+    sents = transcript_sentences(n, os.path.join(tdir, "transcript.txt"), os.path.join(tdir, "lexicon.txt"))
     out = {}
     for _ in range(2):  # the first pass warms allocators and code objects
         tm = {}
@@ -123,7 +224,8 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
         nsamp = int(sum(w.shape[0] for w in wavs.values()))
-        out = {"workload": f"{n} synthetic sentences, text tokens -> 16 kHz waveform, sharded over {world} GPU(s) with no exchange step",
+        out = {"workload": f"{n} sentences cycled from assets/transcript.txt (26 lines) x assets/infore/lexicon.txt, synthetic NAT + HiFi-GAN weights, "
+                           f"text tokens -> 16 kHz waveform, sharded over {world} GPU(s) with no exchange step",
                "sentences": n, "tokens": tm.get("tokens", 0), "frames": tm.get("frames", 0), "frames_max": tm.get("frames_max", 0), "samples": nsamp,
                "duration_model_ms": tm.get("duration_s", 0.0) * 1e3, "host_rules_ms": tm.get("host_rules_s", 0.0) * 1e3,
                "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3, "generator_ms": tm.get("generator_s", 0.0) * 1e3, "total_ms": total * 1e3}
@@ -150,12 +252,23 @@ def main():
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # self-launch: one rank per GPU under torch.distributed.run, the launch line the driver itself uses
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        os.execv(sys.executable, cmd)
+
     # VTTS_DIST_BACKEND=gloo + VTTS_SHARE_GPU=1: a dry run of the N > 1 code path on a ONE-GPU box (every rank on cuda:0,
     # collectives staged through the host) — a development check, never a measurement
     info = vdist.init_process_group(os.environ.get("VTTS_DIST_BACKEND") or None)
     if info.world != args.gpus:
-        if info.rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={info.world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={info.world}: launch one rank per GPU (or unset WORLD_SIZE and let "
+                         f"bench.py launch them)")
     n_gpus = info.world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev_index = 0 if os.environ.get("VTTS_SHARE_GPU") else info.local_rank
@@ -167,7 +280,8 @@ def main():
         gen.set_option("microbatch", args.microbatch)
     if args.streams:
         gen.set_option("streams", args.streams)
-    vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info)
+    bstats = {}
+    vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info, bstats)
 
     B, T = args.batch, args.frames
     # per-rank shard of the global batch: distinct seeded mels, resident in HBM before timing
@@ -226,7 +340,38 @@ def main():
             pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
             pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
 
-    assert bool(torch.isfinite(out[0, :4096]).all()), "non-finite output"
+    # ---- long-form (BASELINE configs[4]): 10 min of 16 kHz audio, exact 512-frame chunks + 13-frame halo, chunk c -> rank c mod N ----
+    longform = None
+    if not args.no_rtf:
+        from viettts_amd.longform import synthesize_chunked
+
+        T10 = 37500  # 600 s * 16000 / 256
+        m10 = torch.from_numpy(synthetic_mel(1, T10, 99)[0]).to(dev)  # every rank holds the utterance's mel (12 MB); no exchange step
+        synthesize_chunked(gen, m10[:2048], 512)  # warm-up of the chunk shapes
+        torch.cuda.synchronize()
+        barrier()
+        tm = {}
+        synthesize_chunked(gen, m10, 512, rank=info.rank, world=n_gpus, timing=tm)
+        tl = torch.tensor([tm.get("first_chunk_s", 0.0), tm["total_s"], float(tm["chunks"])], dtype=torch.float64, device=dev)
+        if n_gpus > 1:
+            tmax, tsum = tl.clone(), tl.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+            tl = torch.stack([tmax[0], tmax[1], tsum[2]])
+        first_s, total_s, nchunks = (float(v) for v in tl.tolist())
+        longform = {
+            "workload": f"one 37500-frame utterance (600 s @16 kHz), 512-frame chunks + 13-frame halo, 16 chunks per batch, "
+                        f"chunk c -> rank c mod {n_gpus} (no exchange step), max over ranks",
+            "first_chunk_ms": first_s * 1e3,
+            "total_ms": total_s * 1e3,
+            "rtf_16000": total_s / 600.0,
+            "samples_per_s": 256 * T10 / total_s,
+            "chunks": int(nchunks),
+        }
+        del m10
+
+    assert bool(torch.isfinite(out).all()), "non-finite output"
+    assert float(out.abs().max()) <= 1.0, "waveform outside tanh's range"
 
     if info.rank == 0:
         samples_per_step = n_gpus * B * 256 * T
@@ -253,6 +398,8 @@ def main():
                 "microbatch": gen.get_option("microbatch"),
                 "streams": gen.get_option("streams"),
             },
+            "weights_broadcast": {"backend": bstats.get("backend"), "ranks_in_group": bstats.get("world"), "bytes": bstats.get("bytes"),
+                                  "ms_rank0": bstats.get("broadcast_ms")},
             "tflops_whole_job": value * FLOP_PER_SAMPLE / 1e12,
             "frac_of_mfma_peak_whole_forward": value * FLOP_PER_SAMPLE / 1e12 / (PEAK_TFLOPS[args.dtype] * n_gpus),
         }
@@ -274,6 +421,8 @@ def main():
         else:
             res["roofline"] = None
 
+        if args.dtype == "bf16" and not args.no_rtf:
+            res["parity_bf16"] = parity_bf16(gen, dev)
         # ---- RTF at batch 1 (BASELINE configs[1]: B=1, T=512) ----
         if not args.no_rtf:
             m1 = torch.from_numpy(synthetic_mel(1, 512, 1234)).to(dev)
@@ -331,23 +480,8 @@ def main():
                 "rtf_22050": med / (131072 / 22050.0),
             }
             g32.close()
-        # ---- long-form (BASELINE configs[4]): 10 min of 16 kHz audio, exact 512-frame chunks + 13-frame halo ----
-        if not args.no_rtf:
-            from viettts_amd.longform import synthesize_chunked
-
-            T10 = 37500  # 600 s * 16000 / 256
-            m10 = torch.from_numpy(synthetic_mel(1, T10, 99)[0]).to(dev)
-            synthesize_chunked(gen, m10[:2048], 512)  # warm-up of the chunk shapes
-            torch.cuda.synchronize()
-            tm = {}
-            synthesize_chunked(gen, m10, 512, timing=tm)
-            res["longform_10min"] = {
-                "workload": "one 37500-frame utterance (600 s @16 kHz), 512-frame chunks + 13-frame halo, 16 chunks per batch, this GPU only",
-                "first_chunk_ms": tm["first_chunk_s"] * 1e3,
-                "total_ms": tm["total_s"] * 1e3,
-                "rtf_16000": tm["total_s"] / 600.0,
-                "chunks": tm["chunks"],
-            }
+        if longform is not None:
+            res["longform_10min"] = longform
         if pipe is not None:
             res["pipeline_256"] = pipe
         if n_gpus == 1 and not args.no_cpu_baseline:

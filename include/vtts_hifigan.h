@@ -123,7 +123,11 @@ int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, fl
  * end as the reference's zero padding (model.py:8-10, "SAME") and skips the tiles beyond it — and the rest of its
  * [hop*T] slot is zero.  The reference has no batching at all (mel2wave.py:20-41 runs one utterance); this is the
  * throughput form of running it once per sentence.
- *   frames_dev : [B] int32, device memory
+ *   frames_dev : [B] int32, device memory.  The counts are read on the device only (no host round trip); a value outside
+ *                [0, T] is CLAMPED into it by every kernel, so a bad count can shorten or lengthen an utterance inside its
+ *                own slot but never reads or writes outside the slot.
+ * Threading: a handle serves ONE call at a time (the ragged state and the profiling counters live on it); forward() makes
+ * the handle's device current (hipSetDevice) and always re-joins its side streams into `stream`, also when a launch fails.
  */
 int vtts_hifigan_forward_ragged(vtts_hifigan* h, const float* mel_dev, const int32_t* frames_dev, int B, int T, float* wav_dev,
                                 void* workspace, size_t workspace_bytes, vtts_stream stream);

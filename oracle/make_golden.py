@@ -12,9 +12,10 @@ time imports this).  What it does:
    (viettts_amd.hifigan.weights.state_dict_to_haiku) reproduces its ``hk_hifi.pickle``
    bit-for-bit;
 4. runs the reference generator forward in fp32 and fp64 on the synthetic mels and stores
-   the outputs (small shapes in full; the BASELINE shape T=512 as a strided sample + sums).
+   the outputs (small shapes in full; the BASELINE shapes T=512 and 64 x 1024 — three rows of the benchmark's own
+   batch — as strided samples + sums).
 
-Usage:  python oracle/make_golden.py
+Usage:  python oracle/make_golden.py [--only CASE ...]
 """
 from __future__ import annotations
 
@@ -133,6 +134,42 @@ def check_converter(tm, conv, cfg, params, workdir: Path):
     return worst, exact, worst2, ref_hk
 
 
+def mint_converter_golden(tm, conv, out: Path):
+    """A weight-norm checkpoint of the TINY architecture (g != ||v||, so the fold matters) and what the REFERENCE converter
+    (convert_torch_model_to_haiku.py:27-62) writes for it: tests/golden/convert_tiny.npz — pins the converter entry point
+    vietTTS.hifigan.convert_torch_model_to_haiku of this repo bit-for-bit (tests/test_weights.py)."""
+    cfg = TINY
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = tm.Generator(cfg_to_h(cfg))
+    gen = torch.Generator().manual_seed(2468)
+    sd = g.state_dict()
+    for spec in conv_specs(cfg):
+        v = sd[spec.torch_prefix + ".weight_v"]
+        sd[spec.torch_prefix + ".weight_v"] = torch.randn(v.shape, generator=gen) * 0.3
+        sd[spec.torch_prefix + ".weight_g"] = torch.rand(sd[spec.torch_prefix + ".weight_g"].shape, generator=gen) + 0.5
+        sd[spec.torch_prefix + ".bias"] = torch.randn(sd[spec.torch_prefix + ".bias"].shape, generator=gen) * 0.1
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        torch.save({"generator": sd}, td / "g_00000001")
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                conv.convert_to_haiku(types.SimpleNamespace(checkpoint_file=str(td / "g_00000001")), cfg_to_h(cfg), torch.device("cpu"))
+            with open(td / "assets/infore/hifigan/hk_hifi.pickle", "rb") as f:
+                ref_hk = pickle.load(f)
+        finally:
+            os.chdir(cwd)
+    arrs = {}
+    for k, v in sd.items():
+        arrs["SD::" + k] = v.numpy()
+    for k, mod in ref_hk.items():
+        for n, a in mod.items():
+            arrs["HK::" + k + "::" + n] = np.ascontiguousarray(a)
+    np.savez_compressed(out / "convert_tiny.npz", **arrs)
+    print(f"[convert_tiny] {len(sd)} checkpoint arrays -> {len(ref_hk)} Haiku modules (reference converter)")
+
+
 def main():
     tm, conv = _import_reference()
     out = REPO / "tests" / "golden"
@@ -146,9 +183,20 @@ def main():
         ("v1_scaled_T37", V1, "scaled", 4321, 2, 37, 77, True),
         ("v1_init_T16", V1, "init", 1234, 1, 16, 1234, True),
         ("v1_scaled_T512", V1, "scaled", 4321, 1, 512, 1234, False),
+        # BASELINE configs[2]'s own batch (bench.py rank 0: synthetic_mel(64, 1024, 1234)); rows 0, 37, 63 of it
+        ("v1_scaled_B64_T1024", V1, "scaled", 4321, 64, 1024, 1234, False),
     ]
+    rows_of = {"v1_scaled_B64_T1024": [0, 37, 63]}
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
+    if only:
+        with open(out / "golden_meta.json") as f:
+            meta = json.load(f)
+    if not only or "convert_tiny" in only:
+        mint_converter_golden(tm, conv, out)
     conv_checked = set()
     for name, cfg, kind, wseed, B, T, mseed, full in cases:
+        if only and name not in only:
+            continue
         params = synthetic_params(cfg, wseed, kind)
         digest = params_digest(params)
         ck = (id(cfg), kind, wseed)
@@ -161,6 +209,9 @@ def main():
             assert w1 < 1e-6 and w2 < 1e-6
             conv_checked.add(ck)
         mel = synthetic_mel(B, T, mseed, cfg.num_mels)
+        rows = rows_of.get(name)
+        if rows is not None:
+            mel = np.ascontiguousarray(mel[rows])
         g32 = reference_generator(tm, cfg, params, torch.float32)
         y32, p32 = reference_forward(g32, mel, torch.float32)
         g64 = reference_generator(tm, cfg, params, torch.float64)
@@ -169,6 +220,8 @@ def main():
               f"|pre| max {np.abs(p64).max():.3f}  sat(|y|>0.99) {(np.abs(y64) > 0.99).mean():.3f}")
         rec = {"cfg": "TINY" if cfg is TINY else "V1", "kind": kind, "wseed": wseed, "B": B, "T": T, "mseed": mseed,
                "params_sha256": digest}
+        if rows is not None:
+            rec["rows"] = rows
         arrs = {}
         if cfg is TINY:
             # weights small enough to commit: fixture independent of the RNG

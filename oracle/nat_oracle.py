@@ -19,8 +19,10 @@ published behaviour of the third-party modules the reference calls (dm-haiku / j
 * ``hk.ResetCore``    state <- initial state where ``should_reset``; at inference the mask (model.py:38) is True
   only from position ``lengths - 1`` on, i.e. after flipping only at the first backward steps, where the state IS
   the initial state (a no-op for ``lengths == L``; kept general here)
-* ``hk.deep_rnn_with_skip_connections([LSTM, LSTM])``: layer 2 sees ``concat[layer-1 output, network input]``;
-  the network output is ``concat`` of both layers' outputs
+* ``hk.deep_rnn_with_skip_connections([LSTM, LSTM])`` (dm-haiku ``recurrent.py``, ``_DeepRNN.__call__``): for layer
+  idx > 0 ``current_inputs = tree_map(concat, inputs, current_inputs)``, i.e. layer 2 sees
+  ``concat[network input, layer-1 output]`` (the INPUT first); ``hk.LSTM`` then appends its own hidden state, so
+  layer 2's weight rows are ``[x ; h1 ; h2]``; the network output is ``concat`` of both layers' outputs
 * ``jax.nn.gelu`` default ``approximate=True`` (tanh form), ``jax.nn.softplus = logaddexp(x, 0)``
 * ``hk.dropout(key, rate, x)``: ``keep = bernoulli(key, 1 - rate)``; ``where(keep, x / (1 - rate), 0)``.  The keys
   come from JAX's threefry PRNG through Haiku's per-scan-step splitting; that stream is NOT restated — callers pass
@@ -204,7 +206,7 @@ def acoustic_inference(
             p = np.where(k2, p * two, dt(0))
         xin = np.concatenate([cond[t], p])
         h1, c1 = lstm_step(xin, h1, c1, w1, b1)
-        h2, c2 = lstm_step(np.concatenate([h1, xin]), h2, c2, w2, b2)
+        h2, c2 = lstm_step(np.concatenate([xin, h1]), h2, c2, w2, b2)  # skip connection: input first
         prev = np.concatenate([h1, h2]) @ wp + bp
         out[t] = prev
     # postnet (:113-121): 4 x (Conv1D(512, 5) + BatchNorm + tanh) + Conv1D(mel_dim, 5); residual added (:151)

@@ -74,3 +74,61 @@ def test_cli_flags_match_reference():
     assert str(a.output) == "clip.wav" and a.sample_rate == 16000 and a.silence_duration == -1 and a.lexicon_file is None
     a = build_parser().parse_args(["--text", "x", "--output", "o.wav", "--sample-rate", "22050", "--silence-duration", "0.2", "--lexicon-file", "l.txt"])
     assert a.text == "x" and a.sample_rate == 22050 and a.silence_duration == 0.2 and a.lexicon_file == "l.txt"
+
+
+# ---- pinned to the reference's OWN functions (oracle/make_text_golden.py lifts them from /root/reference by AST) ----
+import hashlib
+import json
+from pathlib import Path
+
+GOLD = Path(__file__).parent / "golden"
+
+
+def _text_golden():
+    with open(GOLD / "text_golden.json", encoding="utf-8") as f:
+        return json.load(f)
+
+
+def test_config_constants_equal_reference():
+    g = _text_golden()
+    assert load_phonemes_set() == g["phonemes"]
+    assert FLAGS.special_phonemes == g["special_phonemes"]
+    assert FLAGS.sil_index == g["sil_index"] and FLAGS.word_end_index == g["word_end_index"]
+    for k, v in g["flags"].items():
+        assert getattr(FLAGS, k) == v, k
+
+
+def test_lexicon_equals_reference_loader():
+    g = _text_golden()
+    lex = t2m.load_lexicon(GOLD / "text" / "lexicon.txt")
+    assert len(lex) == g["lexicon_entries"]
+    dig = hashlib.sha256("\n".join(f"{k}\t{v}" for k, v in sorted(lex.items())).encode("utf-8")).hexdigest()
+    assert dig == g["lexicon_sha256"]
+
+
+def test_lexicon_malformed_line_raises_like_reference(tmp_path):
+    lex = tmp_path / "lexicon.txt"
+    lex.write_text("a\t a\nbroken line without a tab\n", encoding="utf-8")
+    with pytest.raises(ValueError):  # the reference's dict(lines) (text2mel.py:19)
+        t2m.load_lexicon(lex)
+
+
+def test_normalize_and_tokens_bit_exact_vs_reference_functions():
+    """Every transcript line of the reference's demo (scripts/quick_start.sh:11-12), the whole transcript as ONE --text
+    argument, and adversarial strings: normalised text and token ids equal the reference's own functions' output; where
+    the reference raises (a lexicon phoneme outside the set), so do we, with the same exception type."""
+    g = _text_golden()
+    lex = GOLD / "text" / "lexicon.txt"
+    assert g["n_transcript_lines"] == 26 and len(g["cases"]) >= 39
+    n_tok = 0
+    for c in g["cases"]:
+        norm = nat_normalize_text(c["raw"])
+        assert norm == c["normalized"], c["raw"]
+        if "error" in c:
+            with pytest.raises(ValueError):
+                t2m.text2tokens(norm, lex)
+            assert c["error"] == "ValueError"
+        else:
+            assert t2m.text2tokens(norm, lex) == c["tokens"], c["raw"]
+            n_tok += len(c["tokens"])
+    assert n_tok > 1900

@@ -115,3 +115,23 @@ def test_conv_primitives_against_torch():
                                 padding=(k - s) // 2).permute(0, 2, 1).numpy()
         assert y.shape == (2, 19 * s, 5)
         assert np.abs(y - yt).max() < 1e-12
+
+
+def test_built_reference_archive_matches_golden(golden_dir):
+    """oracle/_ref/torch_generator_v1.pt — the reference's own torch generator compiled by oracle/build_ref.py, the thing
+    bench.py's cpu_baseline times — reproduces the committed golden vectors (minted from the eager reference)."""
+    from pathlib import Path
+
+    import torch
+
+    path = Path(__file__).resolve().parents[1] / "oracle" / "_ref" / "torch_generator_v1.pt"
+    if not path.exists():
+        pytest.skip("oracle/_ref not built (no /root/reference on this box and no prebuilt archive)")
+    rec = _meta(golden_dir)["cases"]["v1_scaled_T37"]
+    g = np.load(golden_dir / "v1_scaled_T37.npz")
+    ts = torch.jit.load(str(path)).eval()
+    mel = synthetic_mel(rec["B"], rec["T"], rec["mseed"])
+    with torch.no_grad():
+        y = ts(torch.from_numpy(mel).permute(0, 2, 1).contiguous())[:, 0].numpy()
+    assert np.abs(y - g["y32"]).max() < 1e-6  # same graph, same weights (thread-count reassociation only)
+    assert np.abs(y - g["y64"]).max() < 2e-5

@@ -690,7 +690,15 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
     if (ws_bytes < need || !ws) return fail(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
     if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail(VTTS_ERR_INVALID, "workspace must be 256-B aligned");
 
-    if (h->dtype == VTTS_BF16) return forward_bf16(h, mel, B, T, wav, ws, s, tap);
+    {
+        hipError_t e = hipSetDevice(h->device);  // side streams / events are created lazily: on THIS handle's device
+        if (e != hipSuccess) return fail(VTTS_ERR_HIP, "hipSetDevice(%d) failed: %s", h->device, hipGetErrorString(e));
+    }
+    if (h->dtype == VTTS_BF16) {
+        const int rc = forward_bf16(h, mel, B, T, wav, ws, s, tap);
+        if (rc) (void)join_streams(h, num_streams(h, B, T), s);  // a failed launch must not leave forked side streams un-joined
+        return rc;
+    }
 
     const vtts_hifigan_cfg& c = h->cfg;
     const int mb = pick_microbatch(h, B, T);
@@ -718,7 +726,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             const Layer& l = h->layers[h->idx_pre];
             Act x{mel + (long)b0 * T * c.num_mels, (long)T * c.num_mels, 1, c.num_mels};
             rc = run_layer(h, l, x, nb, T, 1.0f, nullptr, bufS, ACC_STORE, 1.f, 0, nullptr, s);
-            if (rc) return rc;
+            if (rc) { (void)join_streams(h, nstr, s0); return rc; }
             if (tap.name && !strcmp(tap.name, "conv_pre"))
                 HIP_TRY(hipMemcpyAsync(tap.out + (size_t)b0 * l.cout * T, bufS, (size_t)nb * l.cout * T * sizeof(float),
                                        hipMemcpyDeviceToDevice, s));
@@ -729,7 +737,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             // x = ups_i(leaky_relu(x, 0.1))   (model.py:112-114)
             Act xin{bufS, (long)up.cin * L, L, 1};
             rc = run_layer(h, up, xin, nb, (int)L, 0.1f, nullptr, bufX, ACC_STORE, 1.f, 0, nullptr, s);
-            if (rc) return rc;
+            if (rc) { (void)join_streams(h, nstr, s0); return rc; }
             L *= up.stride;
             const int C = up.cout;
             const long CL = (long)C * L;
@@ -743,7 +751,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                     const Layer& c2 = h->layers[base + 2 * z + 1];
                     // xt = c1(leaky_relu(x, 0.1))                       (model.py:46-47)
                     rc = run_layer(h, c1, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, nullptr, bufT, ACC_STORE, 1.f, 0, nullptr, s);
-                    if (rc) return rc;
+                    if (rc) { (void)join_streams(h, nstr, s0); return rc; }
                     // x = c2(leaky_relu(xt, 0.1)) + x                  (model.py:48-50)
                     if (z < 2) {
                         rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufC, ACC_STORE, 1.f, 0, nullptr, s);
@@ -753,7 +761,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                         const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
                         rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufS, mode, (float)nk, 0, nullptr, s);
                     }
-                    if (rc) return rc;
+                    if (rc) { (void)join_streams(h, nstr, s0); return rc; }
                 }
             }
             if (nk == 1) {
@@ -768,7 +776,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             float* pre = (tap.name && !strcmp(tap.name, "pre_tanh")) ? tap.out + (size_t)b0 * wav_len : nullptr;
             rc = run_layer(h, l, Act{bufS, (long)l.cin * L, L, 1}, nb, (int)L, 0.01f, nullptr, wav + (size_t)b0 * wav_len,
                            ACC_STORE, 1.f, 1, pre, s);
-            if (rc) return rc;
+            if (rc) { (void)join_streams(h, nstr, s0); return rc; }
         }
     }
     return join_streams(h, nstr, s0);
@@ -1039,6 +1047,14 @@ VTTS_API int vtts_hifigan_forward_tap(vtts_hifigan* h, const float* mel_dev, int
     return forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream), t);
 }
 
+// device scratch of the test hooks below: released on every return path
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
 VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const float* x_dev, int B, int L, float slope_in,
                                      const float* res_dev, float* y_dev, vtts_stream stream) {
     if (!h || !key || !x_dev || !y_dev) return fail(VTTS_ERR_INVALID, "null argument");
@@ -1052,7 +1068,8 @@ VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const flo
         // test hook: fp32 channels-last in/out, converted through temporary bf16 buffers
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t nx = (size_t)B * L * l->cin, ny = (size_t)B * L * (l->kind == KIND_CONVT ? l->stride : 1) * l->cout;
-        void *xb = nullptr, *rb = nullptr, *yb = nullptr;
+        DevBuf xbuf, rbuf, ybuf;  // freed on every path (hipFree waits for the device)
+        void *&xb = xbuf.p, *&rb = rbuf.p, *&yb = ybuf.p;
         int rc = VTTS_OK;
         if (is_post) {
             HIP_TRY(hipMalloc(&xb, nx * 2));
@@ -1079,9 +1096,6 @@ VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const flo
             if (!rc && launch_bf16_to_f32(yb, y_dev, ny, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
         }
         hipError_t e = hipStreamSynchronize(st);
-        if (xb) (void)hipFree(xb);
-        if (rb) (void)hipFree(rb);
-        if (yb) (void)hipFree(yb);
         if (!rc && e != hipSuccess) rc = fail(VTTS_ERR_HIP, "run_module failed: %s", hipGetErrorString(e));
         return rc;
     }
@@ -1098,7 +1112,8 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
     if (!l || !l->has_pair) return fail(VTTS_ERR_INVALID, "'%s' is not the first convolution of a fused ResBlock pair (bf16 handles only)", key_c1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)B * L * l->cin;
-    void *xb = nullptr, *yb = nullptr;
+    DevBuf xbuf, ybuf;
+    void *&xb = xbuf.p, *&yb = ybuf.p;
     HIP_TRY(hipMalloc(&xb, n * 2));
     HIP_TRY(hipMalloc(&yb, n * 2));
     int rc = VTTS_OK;
@@ -1106,8 +1121,6 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
     if (!rc) rc = run_pair_bf16(h, *l, xb, B, L, 1.0f, yb, 0, 1.f, st);
     if (!rc && launch_bf16_to_f32(yb, y_dev, n, st) != hipSuccess) rc = fail(VTTS_ERR_HIP, "conversion launch failed");
     hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(xb);
-    (void)hipFree(yb);
     if (!rc && e != hipSuccess) rc = fail(VTTS_ERR_HIP, "run_pair failed: %s", hipGetErrorString(e));
     return rc;
 }

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
     const int mtile = blockIdx.y;
     const int b = blockIdx.z;
     const int Lp = a.L;                                      // rows allocated per utterance
-    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
     if (t0 >= L) return;  // a tile past this utterance's end
 
     const uint4* __restrict__ wsl = reinterpret_cast<const uint4*>(a.wp) + (size_t)mtile * NSTOT * T::SLAB_UNITS;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void conv_post_bf16_k(BConvArgs a, float* __re
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int Lp = a.L;                                      // rows allocated per utterance
-    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
     const long t0 = (long)blockIdx.x * NT;
     if (t0 >= L) return;  // samples past this utterance's end: zero by the caller's memset
     for (int i = tid; i < KS * C; i += 256) ws[i] = a.wf[i];  // Haiku [K][Cin][1] fp32

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int t0 = blockIdx.x * NT2;         // first output time step of this workgroup
     const int b = blockIdx.z;
     const int Lp = a.L;                                      // rows allocated per utterance
-    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
     if (t0 >= L) return;                                     // a tile past this utterance's end: nothing reads its rows
     const int dil = a.dil;
     const int h1 = H2 * dil;                 // c1's symmetric pad (model.py:8-10)

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int lh = lane >> 5;
     const int b = blockIdx.z;
     const int Lp = a.L;                                      // rows allocated per utterance
-    const int L = a.lens ? a.lens[b] * a.len_mul : a.L;      // valid rows of this utterance (ragged batch: the rest reads as zero padding)
+    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
     const int d0 = a.dils[0], d1 = a.dils[1], d2 = a.dils[2];
     const int M = H * (d0 + d1 + d2) + 3 * H;  // invalid margin per side after the three pairs
     const int NT = W - 2 * M;                  // outputs per workgroup

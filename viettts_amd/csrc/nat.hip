@@ -522,15 +522,19 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
 // frame (the recurrence is sequential in frames; sentences are independent):
 //   p = dropout(relu(dropout(relu(prev @ f1)) @ f2))           prenet, no bias, rate 0.5, ALWAYS on (model.py:95-100);
 //                                                               keep[b][f][0|1][PN] bytes (1 = keep, value * 2), nullptr = none
-//   x = [cond_f ; p];  h1 = LSTM1([x ; h1]);  h2 = LSTM2([[h1 ; x] ; h2])      hk.deep_rnn_with_skip_connections
+//   x = [cond_f ; p];  h1 = LSTM1([x ; h1]);  h2 = LSTM2([[x ; h1] ; h2])      hk.deep_rnn_with_skip_connections
+//       (dm-haiku recurrent.py, _DeepRNN.__call__: current_inputs = tree_map(concat, inputs, current_inputs), i.e. the
+//        NETWORK INPUT first, then the previous layer's output; hk.LSTM then appends its own hidden state)
 //   mel_f = [h1 ; h2] @ wp + bp;  prev = mel_f
 // Decoder state in HBM, k-major in groups of four rows with the sentences contiguous (Bp = B rounded up to 64 columns),
 // ping-pong by frame parity:
 //   Z[parity][row / 4][Bp][row % 4]  (one 16-byte load per lane = 4 consecutive rows of its sentence: the LSTM step is bound
 //   by the number of vector-memory instructions a CU can issue, and dword loads of the state were 8 of its 9 per iteration),
 //   rows [ h1 (H) | cond_f (E) | p (PN) | h2 (H) ]:  LSTM1 reads rows [H, H+E+PN) of the current
-//   parity then h1 of the previous one; LSTM2 reads rows [0, H+E+PN) of the current parity then h2 of the previous one —
-//   exactly the row order of the two Haiku weight matrices.  Cell states c1, c2 as [H][Bp].
+//   parity then h1 of the previous one; LSTM2 reads rows [0, H+E+PN) of the current parity then h2 of the previous one.
+//   LSTM1's rows are in Haiku's order; LSTM2's Haiku matrix is [x ; h1 ; h2], so pack() permutes its rows into the
+//   state's [h1 ; x ; h2] order on the host (a product's terms are the same, summed in state-row order).  Cell states
+//   c1, c2 as [H][Bp].
 //
 // nat_dec_lstm_k: gates[32 sentences x (8 units x 4 gates)] per wave on the fp32 matrix cores (v_mfma_f32_32x32x2_f32:
 // M = the slice's 32 gate columns ordered 4*unit + gate, N = 32 sentences, K = 2 per instruction).  With that row order a
@@ -913,7 +917,7 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
     h->add_token_encoder("token_encoder/~/", V, D);
     h->add("lstm/linear", "w", {X + H, 4 * H});          // decoder layer 1: [x ; h1]
     h->add("lstm/linear", "b", {4 * H});
-    h->add("lstm_1/linear", "w", {H + X + H, 4 * H});    // decoder layer 2: [[h1 ; x] ; h2]   (skip connection)
+    h->add("lstm_1/linear", "w", {X + H + H, 4 * H});    // decoder layer 2: [[x ; h1] ; h2]   (skip connection: input first)
     h->add("lstm_1/linear", "b", {4 * H});
     h->add("linear", "w", {2 * H, MEL});                 // projection of concat(h1, h2)
     h->add("linear", "b", {MEL});
@@ -953,18 +957,21 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
         });
     }
     // decoder LSTM weights in MFMA A-fragment order (nat_dec_lstm_k): [slice = 8 units][K/8][lane][4],
-    // element i of lane = W[8*kb + 4*(lane/32) + i][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
+    // element i of lane = W[hrow(8*kb + 4*(lane/32) + i)][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4);
+    // hrow maps a row of the decoder STATE ([h1 | x | h2] for layer 2) to the row of the Haiku matrix ([x | h1 | h2]).
     for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
         const std::string mod = l;
-        const int K = mod == "lstm/linear" ? X + H : H + X + H;
-        h->add_extra(mod + "#mfma", (size_t)K * 4 * H * sizeof(float), [mod, K, H](const NatModel& m, float* out) {
+        const bool skip = mod == "lstm_1/linear";
+        const int K = skip ? X + H + H : X + H;
+        h->add_extra(mod + "#mfma", (size_t)K * 4 * H * sizeof(float), [mod, K, H, X, skip](const NatModel& m, float* out) {
+            auto hrow = [=](int zr) { return !skip ? zr : (zr < H ? X + zr : (zr < H + X ? zr - H : zr)); };
             const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
             const int NIT = K / 8;
             for (int sl = 0; sl < H / 8; ++sl)
                 for (int kb = 0; kb < NIT; ++kb)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
-                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)(8 * kb + 4 * lh + i) * 4 * H + col];
+                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)hrow(8 * kb + 4 * lh + i) * 4 * H + col];
                     }
         });
     }

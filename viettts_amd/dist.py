@@ -114,27 +114,39 @@ def broadcast_packed_weights(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     return blob
 
 
-def setup_model_dp(model, load_fn, info: Optional[RankInfo] = None):
+def setup_model_dp(model, load_fn, info: Optional[RankInfo] = None, stats: Optional[dict] = None):
     """Rank 0 loads + packs the weights (``load_fn(model)`` calls its ``load_params`` and runs on rank 0 only), every other
     rank receives the packed blob: ONE broadcast per model at start-up (HiFi-GAN generator 27.9 MB bf16 / 55.7 MB fp32,
     NAT duration model, NAT acoustic model).  ``model`` offers ``packed_bytes``, ``packed_blob()``, ``adopt_packed(blob)``
-    and ``device`` (Generator, DurationModel, AcousticModel)."""
+    and ``device`` (Generator, DurationModel, AcousticModel).  ``stats`` (a dict) receives ``bytes``, ``broadcast_ms`` (device-
+    synchronised wall time of the one collective on this rank), ``backend`` and ``world`` as the process group reports them."""
+    import time
+
     info = info or rank_info()
     if info.world == 1 or info.rank == 0:
         load_fn(model)
         blob = model.packed_blob()
     else:
         blob = torch.empty(model.packed_bytes, dtype=torch.uint8, device=model.device)
+    if stats is not None:
+        stats.update(bytes=int(blob.numel()), broadcast_ms=0.0, backend=None, world=1)
     if info.world > 1:
+        if blob.is_cuda:
+            torch.cuda.synchronize(blob.device)
+        t0 = time.perf_counter()
         broadcast_packed_weights(blob, 0)
+        if blob.is_cuda:
+            torch.cuda.synchronize(blob.device)
+        if stats is not None:
+            stats.update(broadcast_ms=(time.perf_counter() - t0) * 1e3, backend=dist.get_backend(), world=dist.get_world_size())
         if info.rank != 0:
             model.adopt_packed(blob)
     return model
 
 
-def setup_generator_dp(gen, params_fn, info: Optional[RankInfo] = None):
+def setup_generator_dp(gen, params_fn, info: Optional[RankInfo] = None, stats: Optional[dict] = None):
     """:func:`setup_model_dp` for the generator: ``params_fn()`` returns the Haiku parameter dict (rank 0 only)."""
-    return setup_model_dp(gen, lambda g: g.load_params(params_fn()), info)
+    return setup_model_dp(gen, lambda g: g.load_params(params_fn()), info, stats)
 
 
 def gather_to_rank0(local: torch.Tensor, info: Optional[RankInfo] = None) -> Optional[List[torch.Tensor]]:

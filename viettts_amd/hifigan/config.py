@@ -19,6 +19,7 @@ class FLAGS:
 
     ckpt_dir = Path("./assets/infore/hifigan")
     config_file = Path("assets/hifigan/config.json")
+    dtype = None  # engine of the drop-in mel2wave: None / "f32" = the 1e-4-parity engine, "bf16" = the throughput engine
 
 
 @dataclass(frozen=True)

@@ -7,6 +7,11 @@ none of them observable in the output: the config and the 55.7 MB pickle are rea
 (the reference re-reads both on every call; ``reload()`` drops the cache), and the generator runs on
 MI355X through the HIP library instead of un-jitted XLA-CPU ops.
 
+Engine: the drop-in runs the **fp32** engine by default — the one that meets the reference's numerics (<= 1e-4 max-abs
+against the Haiku generator, BASELINE.json) at ~4e7 samples/s.  ``VTTS_MEL2WAVE_DTYPE=bf16`` in the environment (or
+``FLAGS.dtype = "bf16"``) selects the bf16 throughput engine (~4e8 samples/s batched, max-abs ~1e-2 / 45 dB SNR against
+the same reference: bench.py ``parity_bf16``).
+
 Errors follow the reference: a missing config / checkpoint raises ``FileNotFoundError``; a wrong
 mel shape raises ``ValueError``.
 """
@@ -38,7 +43,15 @@ def reload() -> None:
     _CACHE.clear()
 
 
-def _generator(dtype: str = "f32") -> Generator:
+def _engine_dtype() -> str:
+    d = os.environ.get("VTTS_MEL2WAVE_DTYPE") or getattr(FLAGS, "dtype", None) or "f32"
+    if d not in ("f32", "bf16"):
+        raise ValueError(f"VTTS_MEL2WAVE_DTYPE / FLAGS.dtype must be 'f32' or 'bf16', got {d!r}")
+    return d
+
+
+def _generator(dtype: Optional[str] = None) -> Generator:
+    dtype = dtype or _engine_dtype()
     config_file = str(FLAGS.config_file)  # CWD-relative, as mel2wave.py:21
     ckpt = FLAGS.ckpt_dir / "hk_hifi.pickle"  # mel2wave.py:35
     if not os.path.exists(config_file):

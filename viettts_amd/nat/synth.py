@@ -67,7 +67,7 @@ def synthetic_acoustic_checkpoint(seed: int = 778, vocab_size: int = FLAGS.vocab
     X = 2 * enc + prenet
     pre = "acoustic_model/~/"
     P[pre + "lstm/linear"] = {"w": n(X + dec, 4 * dec, scale=(1.0 / (X + dec)) ** 0.5), "b": n(4 * dec, scale=0.05)}
-    P[pre + "lstm_1/linear"] = {"w": n(dec + X + dec, 4 * dec, scale=(1.0 / (2 * dec + X)) ** 0.5), "b": n(4 * dec, scale=0.05)}
+    P[pre + "lstm_1/linear"] = {"w": n(X + dec + dec, 4 * dec, scale=(1.0 / (2 * dec + X)) ** 0.5), "b": n(4 * dec, scale=0.05)}
     P[pre + "linear"] = {"w": n(2 * dec, mel, scale=(1.0 / (2 * dec)) ** 0.5 * 2.0), "b": n(mel, scale=0.1)}
     P[pre + "linear_1"] = {"w": n(mel, prenet, scale=(2.0 / mel) ** 0.5)}
     P[pre + "linear_2"] = {"w": n(prenet, prenet, scale=(2.0 / prenet) ** 0.5)}
@@ -94,3 +94,18 @@ def synthetic_sentences(n: int = 256, seed: int = 2024):
             body += [int(v) for v in rng.integers(4, 90, size=int(rng.integers(2, 6)))] + [FLAGS.word_end_index]
         out.append([FLAGS.sil_index] + body + [FLAGS.sil_index])
     return out
+
+
+def transcript_sentences(n: int, transcript_fn, lexicon_fn):
+    """BASELINE.json configs[3]'s workload: the first ``n`` non-empty lines CYCLED from the reference's demo
+    transcript (assets/transcript.txt, 26 lines; scripts/quick_start.sh:11-12), each normalised by the CLI's rules
+    (synthesizer.py:21-31) and tokenised against the InfoRe lexicon (text2mel.py:37-58).  Returns token-id lists."""
+    from ..synthesizer import nat_normalize_text
+    from .text2mel import text2tokens
+
+    with open(transcript_fn, "r", encoding="utf-8") as f:
+        lines = [l for l in f.read().split("\n") if l.strip()]
+    if not lines:
+        raise ValueError(f"{transcript_fn}: no sentences")
+    toks = [text2tokens(nat_normalize_text(l), lexicon_fn) for l in lines]
+    return [list(toks[i % len(toks)]) for i in range(n)]

@@ -33,21 +33,22 @@ FRAMES_PER_SECOND_DEN = FLAGS.n_fft // 4
 
 
 def load_lexicon(fn) -> Dict[str, str]:
-    """word<TAB>phonemes per line, lower-cased (text2mel.py:16-19)."""
-    out: Dict[str, str] = {}
+    """word<TAB>phonemes per line, lower-cased and stripped (text2mel.py:16-19).  As the reference's ``dict(lines)``,
+    a line that does not split into exactly two tab-separated fields raises ``ValueError``; a repeated word keeps its
+    LAST entry."""
     with open(fn, "r", encoding="utf-8") as f:
-        for line in f:
-            parts = line.lower().strip().split("\t")
-            if len(parts) == 2:
-                out[parts[0]] = parts[1]
-            elif len(parts) > 2:  # the reference's dict(lines) would raise; keep first two fields
-                out[parts[0]] = parts[1]
-    return out
+        lines = [l.lower().strip().split("\t") for l in f.readlines()]
+    for n, parts in enumerate(lines):
+        if len(parts) != 2:
+            raise ValueError(f"dictionary update sequence element #{n} has length {len(parts)}; 2 is required")
+    return dict(lines)
 
 
 def text2tokens(text: str, lexicon_fn) -> List[int]:
     """sil + per word (special phoneme | lexicon phonemes + word_end | known letters + word_end) + sil
-    (text2mel.py:37-58)."""
+    (text2mel.py:37-58).  Token ids are bit-exact with the reference's own function on its demo workload and on
+    adversarial strings (tests/golden/text_golden.json, minted by oracle/make_text_golden.py); a lexicon entry that
+    names a phoneme outside the set raises ``ValueError`` as the reference's ``phonemes.index`` does."""
     phonemes = load_phonemes_set()
     index = {p: i for i, p in enumerate(phonemes)}
     lexicon = load_lexicon(lexicon_fn)
@@ -56,7 +57,10 @@ def text2tokens(text: str, lexicon_fn) -> List[int]:
         if word in FLAGS.special_phonemes:
             tokens.append(index[word])
         elif word in lexicon:
-            tokens.extend(index[p] for p in lexicon[word].split())
+            for p in lexicon[word].split():
+                if p not in index:
+                    raise ValueError(f"{p!r} is not in list")
+                tokens.append(index[p])
             tokens.append(FLAGS.word_end_index)
         else:
             tokens.extend(index[ch] for ch in word if ch in index)
