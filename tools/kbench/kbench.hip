@@ -16,6 +16,9 @@
 #include "vtts_internal.h"
 
 using namespace vtts;
+namespace vtts {
+hipError_t launch_pair_p_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+}
 
 #define CK(x)                                                                              \
     do {                                                                                   \
@@ -94,7 +97,8 @@ int main(int argc, char** argv) {
     if (argc > 8) dflags = atoi(argv[8]);  // timeline builds of kernels_bf16_rb.hip: experiment switches (results wrong)
     if (argc > 7) impl = atoi(argv[7]);  // kept for old command lines; there is one pair kernel (kernels_bf16_rbg.hip)
     printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
-    auto launch = [&](const BConvArgs& aa) { return launch_pair_g_bf16(C, K, aa, 0); };
+    // impl 0: second generation (two workgroups per CU); impl 1: persistent software-pipelined kernel (kernels_bf16_rbp.hip)
+    auto launch = [&](const BConvArgs& aa) { return impl == 1 ? launch_pair_p_bf16(C, K, aa, 0) : launch_pair_g_bf16(C, K, aa, 0); };
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     const size_t n = (size_t)B * L * C;
@@ -220,6 +224,13 @@ int main(int argc, char** argv) {
                 }
             printf("  %-34s %9.0f\n", nm, cnt ? sm / cnt : 0.0);
         };
+        if (impl == 1) {  // persistent kernel: per-workgroup sums over its run of tiles
+            double c1 = 0, e1 = 0, c2 = 0, nt = 0, tot = 0;
+            for (int i = 0; i < nwg; ++i) { c1 += h[(size_t)i * 16 + 0]; e1 += h[(size_t)i * 16 + 1]; c2 += h[(size_t)i * 16 + 2]; nt += h[(size_t)i * 16 + 3]; tot += h[(size_t)i * 16 + 4]; }
+            printf("persistent kernel, %d workgroups, %.1f tiles each: per tile  c1 loop %.0f  barrier+ep1+barrier %.0f  c2 loop %.0f  = %.0f ticks (loop total / tiles %.0f)\n",
+                   nwg, nt / nwg, c1 / nt, e1 / nt, c2 / nt, (c1 + e1 + c2) / nt, tot / nt);
+            return 0;
+        }
         printf("timeline over %d workgroups (shader-clock ticks, mean per workgroup; thread 0's view):\n", nwg);
         if (impl == 20 || impl >= 30) {
             seg("stage_x + barrier", 0, 1);

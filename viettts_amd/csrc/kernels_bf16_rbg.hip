@@ -23,12 +23,21 @@
 // (emulated: +1.5 %), the raw residual rows kept in LDS at C = 32 (-29 % HBM bytes, 0.8 % slower).  What did help late in the
 // round: one look-ahead load after each MFMA instead of grouped issue (+2.1 %), LeakyReLU as packed multiply + raw v_max
 // and the bias block as the first MFMA's C operand (-30 % VALU instructions per tile, +0.7 %).
+// Round 2: lean loop addressing (VTTS_LEAN: weight fragments by buffer loads with the k-step in an SGPR offset, one row
+// address + swizzle term per tap and v_xad_u32 per k-step for the LDS fragments: 43 -> 21 VALU per 64 MFMAs, 2-5 % per pair
+// launch, profiles/r02_a_pair_kernel_findings.md).  The same treatment of the staging loads and of epilogue 2's row accesses
+// (buffer loads / stores with SGPR row offsets, -200 VALU per tile) measured no faster.  A persistent, software-pipelined
+// one-workgroup-per-CU variant (tools/kbench/experiments/kernels_bf16_rbp.hip) is correct and 15 % SLOWER: see the same file.
 #include <stdio.h>
 #include <string.h>
 
 #include <type_traits>
 
 #include "bf16_common.h"
+
+#ifndef VTTS_LEAN  // lean loop addressing (buffer loads with SGPR offsets, per-tap swizzle terms): A/B switch, tools/kbench
+#define VTTS_LEAN 1
+#endif
 
 namespace vtts {
 
@@ -254,6 +263,52 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             // of a step depend only on its position in the block
             constexpr int UB = NKS < 8 ? NKS : 8;
             static_assert(T::UNROLL_ALL || (UB % RA == 0 && UB % 2 == 0 && NKS % UB == 0), "ring slot / B parity must be compile-time in the block loop");
+#if VTTS_LEAN
+            // Lean addressing of the rolled loop (round 2): the loop's own address arithmetic shares the SIMD's issue port with
+            // the co-resident workgroup's staging / epilogue VALU work.  A fragments: buffer loads, lane offset in a VGPR, the
+            // k-step's offset in an SGPR, the m-block an immediate.  B fragments: one row address + one swizzle term per tap
+            // (a block never straddles taps), (xs ^ ks << 5) + row address per k-step (v_xad_u32), the column block an immediate.
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wconv), 0, (int)T::CONV_BYTES, 0x00020000);
+            const unsigned a_voff = (unsigned)((wm * MR) * 64 + lane) * 16;
+            auto load_a2 = [&](int sa, int slot) {  // flat step sa of this pass (may run past the end: re-read the last step)
+                const int sc = sa < NSTEPS ? sa : NSTEPS - 1;
+                const int tap = sc / NKS, ks = sc - tap * NKS;
+                const int soff = ((tap * KSTEPS + ks0 + ks) * MB) * 1024;
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) {
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + mr * 1024, soff, 0);
+                    af[slot][mr] = __builtin_bit_cast(bf16x8, v);
+                }
+            };
+            auto tap_terms = [&](int tap, unsigned& tapaddr, unsigned& xs) {
+                const int row = rowbase0 + tap * dl;
+                tapaddr = (unsigned)row * PB;
+                xs = (unsigned)(swz_of<SPRB>(row) ^ lh) << 4;
+            };
+            auto load_b2 = [&](unsigned tapaddr, unsigned xs, int ks, int par) {
+                const unsigned addr = tapaddr + (xs ^ (unsigned)(ks << 5));
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + addr + nr * 32 * PB);
+            };
+            auto block = [&](int s0, auto first_tag) {  // the first block of a fresh pass is peeled: its first step reads the bias block
+                const int tap = s0 / NKS, ksb = s0 - tap * NKS;  // this block's tap and first k-step in it
+                unsigned ta, xs, tn, xn;
+                tap_terms(tap, ta, xs);
+                const bool wrap = ksb + UB >= NKS;                // the block's last look-ahead B fragment is the next tap's first
+                const int tapn = tap + 1 < KS ? tap + 1 : KS - 1;
+                tap_terms(wrap ? tapn : tap, tn, xn);
+                const int ksn = wrap ? 0 : ksb + UB;
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    load_a2(s0 + i + PA, (i + PA) % RA);
+                    if (i + 1 < UB) load_b2(ta, xs, ksb + i + 1, (i + 1) & 1);
+                    else load_b2(tn, xn, ksn, (i + 1) & 1);
+                    mfma_step(i % RA, i & 1, decltype(first_tag)::value && i == 0);
+                    pin_step(true);
+                }
+            };
+#else
             auto block = [&](int s0, auto first_tag) {  // the first block of a fresh pass is peeled: its first step reads the bias block
 #pragma unroll
                 for (int i = 0; i < UB; ++i) {
@@ -264,6 +319,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     pin_step(true);
                 }
             };
+#endif
             block(0, std::integral_constant<bool, FRESH>{});
 #pragma nounroll
             for (int s0 = UB; s0 < NSTEPS; s0 += UB) block(s0, std::false_type{});
