@@ -58,15 +58,14 @@ def cpu_baseline_reference(budget_s: float = 25.0):
     carried to this box under oracle/_ref/.  Same synthetic weights (W_scaled seed 4321) and mels (seed 1234) as the GPU
     run.  B=1 x T=512: 1 warm-up + median of 5 (RTF); B=4 x T=1024: median of 2 (throughput) while the time budget lasts.
     Returns None when the archive is absent."""
-    path = os.path.join(REPO, "oracle", "_ref", "torch_generator_v1.pt")
-    if not os.path.exists(path):
-        return None
+    from oracle.build_ref import load_reference_archive  # the checker's loader (cpu_baseline leg only)
     from viettts_amd.hifigan.weights import haiku_to_state_dict
 
     ncpu = _host_threads()
-    ts = torch.jit.load(path, map_location="cpu").eval()
     sd = {k: torch.from_numpy(v) for k, v in haiku_to_state_dict(V1, synthetic_params(V1, 4321, "scaled")).items()}
-    ts.load_state_dict(sd, strict=True)
+    ts = load_reference_archive(sd)
+    if ts is None:
+        return None
     # BASELINE.md §4 says torch.set_num_threads(os.cpu_count()); on a 256-thread host that measured 52 s per 512-frame utterance
     # (2.5e3 samples/s: OpenMP oversubscription on 32-channel convolutions), 70x slower than 8 threads.  A baseline that
     # handicaps the reference is no baseline: calibrate the thread count on a short input (ascending, stop once it gets
@@ -109,7 +108,7 @@ def cpu_baseline_reference(budget_s: float = 25.0):
         "unit": "samples/s",
         "cores": int(cores),
         "kind": "reference",
-        "impl": "reference-torch: vietTTS/hifigan/torch_model.py::Generator (TorchScript archive oracle/_ref/torch_generator_v1.pt), "
+        "impl": "reference-torch: vietTTS/hifigan/torch_model.py::Generator (TorchScript archive oracle/_ref/torch_generator_v1.pt.gz), "
                 "fp32, torch CPU threads = cores; the reference's JAX-CPU path is not installable offline (no jax/jaxlib/haiku)",
         "sample": f"B=1 x T=512 frames (131072 samples), 1 warm-up + median of {n1}",
         "ms": med1 * 1e3,

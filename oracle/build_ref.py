@@ -5,8 +5,10 @@ model the Haiku weights are converted from (the JAX/Haiku pat
 sources cannot travel (/root/reference does not exist on the GPU box, and reference sources are never copied into this
 repo), so — exactly as a C reference would be compiled to ``oracle/_ref/*.so`` — the module is imported HERE from where
 it lies, ``remove_weight_norm()`` applied (as the reference's converter does, convert_torch_model_to_haiku.py:32), and
-compiled with ``torch.jit.trace`` into ``oracle/_ref/torch_generator_v1.pt``: a TorchScript archive of the reference's
-own graph of aten ops (conv1d / conv_transpose1d / leaky_relu / add / div / tanh), parameters as loadable state.
+compiled with ``torch.jit.trace`` into ``oracle/_ref/torch_generator_v1.pt.gz``: a TorchScript archive of the reference's
+own graph of aten ops (conv1d / conv_transpose1d / leaky_relu / add / div / tanh), parameters as loadable state.  The
+archive is written with ZEROED parameters and gzip-ed (56 MB -> ~60 KB: every gpurun call pushes the tree); its users load
+the weights they want with ``load_state_dict`` (:func:`load_reference_archive`).
 ``oracle/_ref/`` is git-ignored (built artefact) but travels with gpurun like the HIP library.
 
 Consumers: ``bench.py::cpu_baseline`` (kind "reference") and tests/test_oracle_golden.py (the archive against the
@@ -25,6 +27,26 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parents[1]
 REF = Path("/root/reference")
 OUT = REPO / "oracle" / "_ref"
+
+
+ARCHIVE = OUT / "torch_generator_v1.pt.gz"
+
+
+def load_reference_archive(state_dict=None):
+    """The built reference generator (TorchScript, CPU), optionally with ``state_dict`` (torch tensors, the reference's own
+    ``conv_pre.weight`` ... names) loaded; ``None`` if the archive is not there."""
+    import gzip
+    import io
+
+    import torch
+
+    if not ARCHIVE.exists():
+        return None
+    with gzip.open(ARCHIVE, "rb") as f:
+        ts = torch.jit.load(io.BytesIO(f.read()), map_location="cpu").eval()
+    if state_dict is not None:
+        ts.load_state_dict(state_dict, strict=True)
+    return ts
 
 
 def main() -> int:
@@ -56,13 +78,26 @@ def main() -> int:
     with torch.no_grad():
         d = float((ts(x2) - g(x2)).abs().max())
     assert d == 0.0, f"traced reference differs from the eager reference at a new shape: {d}"
-    path = OUT / "torch_generator_v1.pt"
-    ts.save(str(path))
+    import gzip
+    import io
+
+    nparam = int(sum(v.numel() for v in ts.state_dict().values()))
+    with torch.no_grad():
+        for v in ts.state_dict().values():
+            v.zero_()  # users load their own weights; zeros make the archive ~60 KB
+    bio = io.BytesIO()
+    torch.jit.save(ts, bio)
+    path = ARCHIVE
+    with gzip.open(path, "wb", compresslevel=6) as f:
+        f.write(bio.getvalue())
+    old = OUT / "torch_generator_v1.pt"
+    if old.exists():
+        old.unlink()
     meta = {"source": "vietTTS/hifigan/torch_model.py:156-218 (Generator, weight norm removed), torch.jit.trace",
             "torch": torch.__version__, "state_dict_keys": len(ts.state_dict()),
-            "params": int(sum(v.numel() for v in ts.state_dict().values()))}
+            "params": nparam}
     (OUT / "torch_generator_v1.json").write_text(json.dumps(meta, indent=1))
-    print(f"built {path} ({path.stat().st_size / 1e6:.1f} MB, {meta['params']} parameters)")
+    print(f"built {path} ({path.stat().st_size / 1e3:.0f} KB, {meta['params']} parameters)")
     return 0
 
 

@@ -120,16 +120,17 @@ def test_conv_primitives_against_torch():
 def test_built_reference_archive_matches_golden(golden_dir):
     """oracle/_ref/torch_generator_v1.pt — the reference's own torch generator compiled by oracle/build_ref.py, the thing
     bench.py's cpu_baseline times — reproduces the committed golden vectors (minted from the eager reference)."""
-    from pathlib import Path
-
     import torch
 
-    path = Path(__file__).resolve().parents[1] / "oracle" / "_ref" / "torch_generator_v1.pt"
-    if not path.exists():
-        pytest.skip("oracle/_ref not built (no /root/reference on this box and no prebuilt archive)")
+    from oracle.build_ref import load_reference_archive
+    from viettts_amd.hifigan.weights import haiku_to_state_dict
+
     rec = _meta(golden_dir)["cases"]["v1_scaled_T37"]
     g = np.load(golden_dir / "v1_scaled_T37.npz")
-    ts = torch.jit.load(str(path)).eval()
+    sd = {k: torch.from_numpy(v) for k, v in haiku_to_state_dict(V1, synthetic_params(V1, rec["wseed"], rec["kind"])).items()}
+    ts = load_reference_archive(sd)
+    if ts is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this box and no prebuilt archive)")
     mel = synthetic_mel(rec["B"], rec["T"], rec["mseed"])
     with torch.no_grad():
         y = ts(torch.from_numpy(mel).permute(0, 2, 1).contiguous())[:, 0].numpy()
