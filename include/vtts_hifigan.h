@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define VTTS_ABI_VERSION 1
+#define VTTS_ABI_VERSION 2
 
 typedef enum vtts_status {
     VTTS_OK = 0,
@@ -47,7 +47,8 @@ typedef enum vtts_dtype {
 /*
  * The architecture-defining fields Generator.__init__ reads from the JSON config
  * (vietTTS/hifigan/model.py:81-106; assets/hifigan/config.json:2,11-15,19).
- * Only resblock == "1" (ResBlock1, model.py:13-51) exists on this path.
+ * resblock: 1 = ResBlock1 (model.py:13-51; three dilations per kernel size; every engine), 2 = ResBlock2 (model.py:54-74;
+ * two dilations per kernel size, the third entry is ignored; VTTS_F32 handles only).  0 is read as 1.
  */
 typedef struct vtts_hifigan_cfg {
     int32_t num_mels;                                        /* 80  */
@@ -58,6 +59,7 @@ typedef struct vtts_hifigan_cfg {
     int32_t num_kernels;                                     /* 3   */
     int32_t resblock_kernel_sizes[VTTS_MAX_KERNELS];         /* 3,7,11      */
     int32_t resblock_dilation_sizes[VTTS_MAX_KERNELS][3];    /* 1,3,5 each  */
+    int32_t resblock;                                        /* 1 (config.json "resblock": "1") or 2 */
 } vtts_hifigan_cfg;
 
 typedef struct vtts_hifigan vtts_hifigan; /* opaque */

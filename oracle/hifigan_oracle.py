@@ -106,6 +106,17 @@ def resblock1(params: Dict, n: int, x: np.ndarray, k: int, dilations) -> np.ndar
     return x
 
 
+def resblock2(params: Dict, n: int, x: np.ndarray, k: int, dilations) -> np.ndarray:
+    """ResBlock2.__call__ — vietTTS/hifigan/model.py:69-74: per convolution ``x = c(leaky_relu(x)) + x``.  Module names as the
+    Haiku model creates them: ``res_block1_{n}`` (model.py:105) with default-named convolutions ``conv1_d``, ``conv1_d_1``."""
+    for z, d in enumerate(dilations):
+        c = params[f"generator/~/res_block1_{n}/~/conv1_d" + ("" if z == 0 else f"_{z}")]
+        xt = leaky_relu(x, LRELU_SLOPE)
+        xt = conv1d(xt, c["w"], c["b"], int(d), get_padding(k, int(d)))
+        x = xt + x
+    return x
+
+
 def generator_forward(params: Dict, mel: np.ndarray, cfg=None, dtype=np.float64, return_pre_tanh: bool = False, taps: Optional[List] = None):
     """Generator.__call__ — vietTTS/hifigan/model.py:109-125.
 
@@ -130,7 +141,8 @@ def generator_forward(params: Dict, mel: np.ndarray, cfg=None, dtype=np.float64,
             taps.append((f"ups_{i}", x))
         xs = None
         for j in range(nk):  # :116-120
-            r = resblock1(p, i * nk + j, x, int(cfg.resblock_kernel_sizes[j]), cfg.resblock_dilation_sizes[j])
+            rb = resblock2 if getattr(cfg, "resblock", "1") == "2" else resblock1  # model.py:86
+            r = rb(p, i * nk + j, x, int(cfg.resblock_kernel_sizes[j]), cfg.resblock_dilation_sizes[j])
             if taps is not None:
                 taps.append((f"res_block1_{i * nk + j}", r))
             xs = r if xs is None else xs + r

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import hifigan_oracle as orc
-from viettts_amd.hifigan.config import TINY, V1
+from viettts_amd.hifigan.config import TINY, TINY2, V1
 from viettts_amd.hifigan.synth import params_digest, synthetic_mel, synthetic_params
 from viettts_amd.hifigan.weights import conv_specs
 
@@ -181,6 +181,34 @@ def test_tiny_architecture_rng_independent(golden_dir, dev):
     gen.close()
     assert np.abs(wav.cpu().numpy() - g["y64"]).max() < TIGHT
     assert np.abs(pre.cpu().numpy() - g["pre64"]).max() < TIGHT
+
+
+def test_resblock2_generator_vs_reference_golden(golden_dir, dev):
+    """ResBlock2 generators (vietTTS/hifigan/model.py:54-74, selected by config "resblock": "2", model.py:86): the fp32 engine
+    against the reference's own torch generator (torch_model.py:117-148) on fixture weights — kernel sizes 3 / 5 / 7, rates
+    (1, 2) / (2, 6) / (3, 12), two residual convolutions per block, MRF mean over the three blocks.  Parameter names are the
+    ones the Haiku MODEL creates (res_block1_N/~/conv1_d, conv1_d_1)."""
+    from viettts_amd import _lib
+    from viettts_amd.hifigan.generator import Generator
+
+    g = np.load(golden_dir / "tiny2_scaled_T12.npz")
+    params = {}
+    for name in g.files:
+        if name.startswith("W::"):
+            _, key, which = name.split("::")
+            params.setdefault(key, {})[which] = g[name]
+    assert "generator/~/res_block1_0/~/conv1_d_1" in params and len(params) == 1 + 4 + 12 * 2 + 1
+    gen = Generator(TINY2, device=dev)
+    gen.load_params(params)
+    wav, pre = gen.forward_tap(torch.from_numpy(g["mel"]).to(dev), "pre_tanh")
+    torch.cuda.synchronize()
+    assert np.abs(wav.cpu().numpy() - g["y64"]).max() < 2e-5
+    assert np.abs(pre.cpu().numpy() - g["pre64"]).max() < 2e-5
+    want = orc.generator_forward(params, g["mel"], TINY2, np.float64)[..., 0]
+    assert np.abs(wav.cpu().numpy() - want).max() < 2e-5
+    gen.close()
+    with pytest.raises(_lib.VttsError):  # the bf16 kernels are fused ResBlock1 pairs
+        Generator(TINY2, device=dev, dtype="bf16")
 
 
 def test_baseline_config2_shape(golden_dir, gen_v1, dev):

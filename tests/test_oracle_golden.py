@@ -7,10 +7,10 @@ import pytest
 
 from oracle.hifigan_oracle import (conv1d, conv1d_transpose, conv_transpose_same_pads, flops_per_frame,
                                    generator_forward, get_padding, mel2wave_oracle)
-from viettts_amd.hifigan.config import TINY, V1
+from viettts_amd.hifigan.config import TINY, TINY2, V1
 from viettts_amd.hifigan.synth import params_digest, synthetic_mel, synthetic_params
 
-CFG = {"V1": V1, "TINY": TINY}
+CFG = {"V1": V1, "TINY": TINY, "TINY2": TINY2}
 
 
 def _meta(golden_dir):
@@ -27,7 +27,7 @@ def _tiny_params_from_fixture(g):
     return params
 
 
-@pytest.mark.parametrize("case", ["tiny_scaled_T12", "v1_scaled_T8", "v1_scaled_T37", "v1_init_T16"])
+@pytest.mark.parametrize("case", ["tiny_scaled_T12", "tiny2_scaled_T12", "v1_scaled_T8", "v1_scaled_T37", "v1_init_T16"])
 def test_oracle_matches_reference_full(golden_dir, case):
     rec = _meta(golden_dir)["cases"][case]
     cfg = CFG[rec["cfg"]]
@@ -54,6 +54,16 @@ def test_tiny_fixture_is_rng_independent(golden_dir):
     g = np.load(golden_dir / "tiny_scaled_T12.npz")
     params = _tiny_params_from_fixture(g)
     y, pre = generator_forward(params, g["mel"], TINY, np.float64, return_pre_tanh=True)
+    assert np.abs(y[..., 0] - g["y64"]).max() < 1e-12
+    assert np.abs(pre[..., 0] - g["pre64"]).max() < 1e-12
+
+
+def test_resblock2_fixture_is_rng_independent(golden_dir):
+    """ResBlock2 (model.py:54-74) against the reference's torch generator built with "resblock": "2", on fixture weights."""
+    g = np.load(golden_dir / "tiny2_scaled_T12.npz")
+    params = _tiny_params_from_fixture(g)
+    assert sum(1 for k in params if "res_block1_" in k) == 24  # 12 blocks x 2 convolutions
+    y, pre = generator_forward(params, g["mel"], TINY2, np.float64, return_pre_tanh=True)
     assert np.abs(y[..., 0] - g["y64"]).max() < 1e-12
     assert np.abs(pre[..., 0] - g["pre64"]).max() < 1e-12
 

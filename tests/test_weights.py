@@ -4,7 +4,7 @@ import pickle
 import numpy as np
 import pytest
 
-from viettts_amd.hifigan.config import TINY, V1, HifiganConfig
+from viettts_amd.hifigan.config import TINY, TINY2, V1, HifiganConfig
 from viettts_amd.hifigan.synth import synthetic_params
 from viettts_amd.hifigan.weights import (check_params, conv_specs, haiku_to_state_dict, load_haiku_pickle, num_parameters,
                                           save_haiku_pickle, state_dict_to_haiku, torch_weight_to_haiku)
@@ -101,3 +101,21 @@ def test_converter_entry_point_bit_exact_vs_reference_converter(tmp_path, monkey
             assert got[key][which].dtype == np.float32
             assert np.array_equal(got[key][which], want[key][which]), (key, which)
     check_params(TINY, got)
+
+
+def test_resblock2_inventory_and_names():
+    """ResBlock2 generators (model.py:54-74): 2 convolutions per block under the names the Haiku model creates
+    (res_block1_N: model.py:105; default hk.Conv1D names: model.py:58-66), upstream torch names resblocks.N.convs.Z."""
+    specs = conv_specs(TINY2)
+    assert len(specs) == 1 + 4 + 12 * 2 + 1
+    by = {s.key: s for s in specs}
+    a, b = by["generator/~/res_block1_4/~/conv1_d"], by["generator/~/res_block1_4/~/conv1_d_1"]
+    assert (a.k, a.dilation, b.dilation, a.torch_prefix, b.torch_prefix) == (5, 2, 6, "resblocks.4.convs.0", "resblocks.4.convs.1")
+    params = synthetic_params(TINY2, 1, "scaled")
+    check_params(TINY2, params)
+    back = state_dict_to_haiku(TINY2, haiku_to_state_dict(TINY2, params))
+    assert all(np.array_equal(back[k][n], params[k][n]) for k in params for n in ("w", "b"))
+    with pytest.raises(ValueError):
+        HifiganConfig(resblock="2").validate()  # ResBlock2 takes two dilations per kernel size
+    with pytest.raises(ValueError):
+        HifiganConfig(resblock="3").validate()

@@ -98,7 +98,11 @@ int main(int argc, char** argv) {
     if (argc > 7) impl = atoi(argv[7]);  // kept for old command lines; there is one pair kernel (kernels_bf16_rbg.hip)
     printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
     // impl 0: second generation (two workgroups per CU); impl 1: persistent software-pipelined kernel (kernels_bf16_rbp.hip)
+#ifdef KBENCH_NO_P
+    auto launch = [&](const BConvArgs& aa) { return launch_pair_g_bf16(C, K, aa, 0); };
+#else  // build with tools/kbench/experiments/kernels_bf16_rbp.hip on the command line
     auto launch = [&](const BConvArgs& aa) { return impl == 1 ? launch_pair_p_bf16(C, K, aa, 0) : launch_pair_g_bf16(C, K, aa, 0); };
+#endif
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
     const size_t n = (size_t)B * L * C;

@@ -11,7 +11,7 @@ import os
 from pathlib import Path
 from typing import Optional
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_UPSAMPLES = 8
 MAX_KERNELS = 4
 
@@ -106,6 +106,7 @@ class CfgStruct(C.Structure):
         ("num_kernels", C.c_int32),
         ("resblock_kernel_sizes", C.c_int32 * MAX_KERNELS),
         ("resblock_dilation_sizes", (C.c_int32 * 3) * MAX_KERNELS),
+        ("resblock", C.c_int32),
     ]
 
 
@@ -239,6 +240,7 @@ def make_cfg(cfg) -> CfgStruct:
     s.num_kernels = cfg.num_kernels
     for j, (k, d) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
         s.resblock_kernel_sizes[j] = int(k)
-        for z in range(3):
+        for z in range(len(d)):
             s.resblock_dilation_sizes[j][z] = int(d[z])
+    s.resblock = int(cfg.resblock)
     return s

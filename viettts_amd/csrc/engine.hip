@@ -241,6 +241,17 @@ int build_layers(vtts_hifigan* h) {
         for (int j = 0; j < c.num_kernels; ++j) {
             const std::string base = "generator/~/res_block1_" + std::to_string(n) + "/~/";
             int first = -1;
+            if (c.resblock == 2) {
+                // ResBlock2 (model.py:54-74): two convolutions, default hk.Conv1D names inside the module named res_block1_N (model.py:105)
+                for (int z = 0; z < 2; ++z) {
+                    int i1 = add(base + (z == 0 ? std::string("conv1_d") : "conv1_d_" + std::to_string(z)), KIND_CONV, cout, cout,
+                                 c.resblock_kernel_sizes[j], c.resblock_dilation_sizes[j][z], 1);
+                    if (z == 0) first = i1;
+                }
+                h->idx_res.push_back(first);  // layers first, first + 1
+                ++n;
+                continue;
+            }
             for (int z = 0; z < 3; ++z) {
                 int i1 = add(base + "convs1_" + std::to_string(z), KIND_CONV, cout, cout, c.resblock_kernel_sizes[j],
                              c.resblock_dilation_sizes[j][z], 1);
@@ -746,6 +757,21 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             for (int j = 0; j < nk; ++j) {
                 const int base = h->idx_res[i * nk + j];
                 const float* cur = bufX;
+                if (c.resblock == 2) {
+                    // ResBlock2: x = c_z(leaky_relu(x, 0.1)) + x, z = 0, 1 (model.py:69-74); the MRF sum / mean in the last epilogue
+                    for (int z = 0; z < 2; ++z) {
+                        const Layer& cz = h->layers[base + z];
+                        if (z == 0) {
+                            rc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, bufC, ACC_STORE, 1.f, 0, nullptr, s);
+                            cur = bufC;
+                        } else {
+                            const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
+                            rc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, bufS, mode, (float)nk, 0, nullptr, s);
+                        }
+                        if (rc) { (void)join_streams(h, nstr, s0); return rc; }
+                    }
+                    continue;
+                }
                 for (int z = 0; z < 3; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
                     const Layer& c2 = h->layers[base + 2 * z + 1];
@@ -809,14 +835,19 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
     for (int j = 0; j < cfg->num_kernels; ++j) {
         if (cfg->resblock_kernel_sizes[j] < 1 || cfg->resblock_kernel_sizes[j] % 2 == 0)
             return fail(VTTS_ERR_INVALID, "resblock kernel size %d must be odd", cfg->resblock_kernel_sizes[j]);
-        for (int z = 0; z < 3; ++z)
+        for (int z = 0; z < (cfg->resblock == 2 ? 2 : 3); ++z)
             if (cfg->resblock_dilation_sizes[j][z] < 1) return fail(VTTS_ERR_INVALID, "dilation must be >= 1");
     }
+    if (cfg->resblock != 0 && cfg->resblock != 1 && cfg->resblock != 2)
+        return fail(VTTS_ERR_INVALID, "resblock must be 1 (ResBlock1) or 2 (ResBlock2), got %d", cfg->resblock);
+    if (cfg->resblock == 2 && dtype != VTTS_F32)
+        return fail(VTTS_ERR_INVALID, "ResBlock2 generators run on the fp32 engine (the bf16 kernels are fused ResBlock1 pairs)");
     if (device < 0) return fail(VTTS_ERR_INVALID, "device %d out of range", device);
     // the device itself is first touched in pack()/bind_packed(): planning needs no GPU
     auto* h = new (std::nothrow) vtts_hifigan();
     if (!h) return fail(VTTS_ERR_NOMEM, "host allocation failed");
     h->cfg = *cfg;
+    if (h->cfg.resblock == 0) h->cfg.resblock = 1;
     h->device = device;
     h->dtype = dtype;
     const int rc = build_layers(h);

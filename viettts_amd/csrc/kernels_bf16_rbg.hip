@@ -470,9 +470,21 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #ifndef VTTS_EXP_LDS_PAD  // kernel-development switch (tools/kbench): extra LDS per workgroup, e.g. 20000 = one workgroup per CU
 #define VTTS_EXP_LDS_PAD 0
 #endif
-template <int KS> using G128 = GTile<128, KS, 256, 2, 2, 3, 2>;
-template <int KS> using G64 = GTile<64, KS, 512, 1, 4, 3, 2>;
-template <int KS> using G32 = GTile<32, KS, 512, 1, 4, 3, 2>;
+#ifndef VTTS_G64_N1  // tile-geometry experiments (tools/kbench): time steps per tile and workgroups per CU of the narrow stages
+#define VTTS_G64_N1 512
+#define VTTS_G64_WG 2
+#endif
+#ifndef VTTS_G32_N1
+#define VTTS_G32_N1 512
+#define VTTS_G32_WG 2
+#endif
+#ifndef VTTS_G128K3_N1
+#define VTTS_G128K3_N1 256
+#define VTTS_G128K3_WG 2
+#endif
+template <int KS> using G128 = GTile<128, KS, KS == 3 ? VTTS_G128K3_N1 : 256, 2, 2, 3, KS == 3 ? VTTS_G128K3_WG : 2>;
+template <int KS> using G64 = GTile<64, KS, VTTS_G64_N1, 1, 4, 3, VTTS_G64_WG>;
+template <int KS> using G32 = GTile<32, KS, VTTS_G32_N1, 1, 4, 3, VTTS_G32_WG>;
 template <int KS> using G256 = GTile<256, KS, 128, 4, 1, 3, 2, 128>;
 template <class T>
 static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {

@@ -61,10 +61,8 @@ class HifiganConfig:
         return self.upsample_initial_channel // (2 ** (i + 1))
 
     def validate(self) -> None:
-        if self.resblock != "1":
-            # ResBlock2 / V2-V3 checkpoints are not loadable in the reference either
-            # (module names at model.py:105 vs convert_torch_model_to_haiku.py:45-46).
-            raise ValueError("only resblock='1' (ResBlock1) is supported, got %r" % (self.resblock,))
+        if self.resblock not in ("1", "2"):
+            raise ValueError("resblock must be '1' (ResBlock1, model.py:13-51) or '2' (ResBlock2, model.py:54-74), got %r" % (self.resblock,))
         if len(self.upsample_rates) != len(self.upsample_kernel_sizes):
             raise ValueError("upsample_rates and upsample_kernel_sizes differ in length")
         if len(self.resblock_kernel_sizes) != len(self.resblock_dilation_sizes):
@@ -72,9 +70,10 @@ class HifiganConfig:
         for k in self.resblock_kernel_sizes:
             if k % 2 != 1:
                 raise ValueError("resblock kernel sizes must be odd (length-preserving padding)")
+        nd = 3 if self.resblock == "1" else 2
         for d in self.resblock_dilation_sizes:
-            if len(d) != 3:
-                raise ValueError("ResBlock1 takes exactly 3 dilations per kernel size")
+            if len(d) != nd:
+                raise ValueError("ResBlock%s takes exactly %d dilations per kernel size (model.py:%s)" % (self.resblock, nd, "15,43" if nd == 3 else "55,68"))
         if self.upsample_initial_channel % (2 ** self.num_upsamples) != 0:
             raise ValueError("upsample_initial_channel must be divisible by 2**num_upsamples")
 
@@ -112,3 +111,11 @@ V1 = HifiganConfig()
 # 3x3 ResBlock1 grid, hop 256) used by fixtures whose weights are small enough to
 # commit under tests/golden/.
 TINY = HifiganConfig(upsample_initial_channel=32)
+
+# The same, with ResBlock2 (vietTTS/hifigan/model.py:54-74: two convolutions per block, each with its own residual) and the
+# kernel sizes / dilations of the upstream V3 config.  The reference builds this generator (model.py:86) but cannot LOAD a
+# checkpoint for it: its converter names the modules res_block2_N/~/convs_Z (convert_torch_model_to_haiku.py:45-46) while the
+# Haiku model creates res_block1_N/~/conv1_d[_1] (model.py:105, default hk.Conv1D names).  Here the parameter dict uses the
+# names the Haiku MODEL creates, and the converter of this repo writes those.
+TINY2 = HifiganConfig(resblock="2", upsample_initial_channel=32, resblock_kernel_sizes=(3, 5, 7),
+                      resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)))

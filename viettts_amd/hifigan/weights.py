@@ -72,6 +72,15 @@ def conv_specs(cfg: HifiganConfig) -> List[ConvSpec]:
         ch = cfg.stage_channels(i)
         for k, dil in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
             blk = []
+            if cfg.resblock == "2":
+                # ResBlock2 (model.py:54-74): the module keeps the name res_block1_N (model.py:105) and its two hk.Conv1D get the
+                # default names conv1_d, conv1_d_1 (model.py:58-66); upstream torch: resblocks.N.convs.Z (torch_model.py:119-141)
+                for z in range(2):
+                    blk.append(ConvSpec(f"generator/~/res_block1_{n}/~/conv1_d" + ("" if z == 0 else f"_{z}"), f"resblocks.{n}.convs.{z}", "conv",
+                                        ch, ch, int(k), int(dil[z])))
+                res.append(blk)
+                n += 1
+                continue
             for z in range(3):  # ResBlock1.__call__ runs convs1_z then convs2_z (model.py:45-49)
                 blk.append(
                     ConvSpec(f"generator/~/res_block1_{n}/~/convs1_{z}", f"resblocks.{n}.convs1.{z}", "conv", ch, ch, int(k), int(dil[z]))
