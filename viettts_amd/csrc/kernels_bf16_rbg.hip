@@ -486,6 +486,14 @@ template <int KS> using G128 = GTile<128, KS, KS == 3 ? VTTS_G128K3_N1 : 256, 2,
 template <int KS> using G64 = GTile<64, KS, VTTS_G64_N1, 1, 4, 3, VTTS_G64_WG>;
 template <int KS> using G32 = GTile<32, KS, VTTS_G32_N1, 1, 4, 3, VTTS_G32_WG>;
 template <int KS> using G256 = GTile<256, KS, 128, 4, 1, 3, 2, 128>;
+// narrow tiles for SMALL launches (batch-1 latency: a 512-frame utterance is 35 wide tiles at C = 256, 134 at C = 128 — a
+// fraction of the 512 workgroup slots): half the time steps per workgroup, twice the workgroups.  Same per-element
+// accumulation order (the k loop), so the samples are bit-identical to the wide tiles'.
+template <int KS> using G256S = GTile<256, KS, 64, 4, 1, 3, 2, 128>;
+template <int KS> using G128S = GTile<128, KS, 128, 2, 2, 3, 2>;
+template <int KS> using G64S = GTile<64, KS, 256, 1, 4, 3, 2>;
+template <int KS> using G32S = GTile<32, KS, 256, 1, 4, 3, 2>;
+constexpr long G_MIN_WGS = 384;  // below this many wide-tile workgroups (1.5 per CU slot pair) the narrow tile is launched
 template <class T>
 static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     static bool attr_done = false;
@@ -513,10 +521,10 @@ static hipError_t launch_g_ks(const BConvArgs& a, int K, hipStream_t s) {
 
 hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
     switch (C) {
-        case 256: return launch_g_ks<G256>(a, K, s);
-        case 128: return launch_g_ks<G128>(a, K, s);
-        case 64: return launch_g_ks<G64>(a, K, s);
-        case 32: return launch_g_ks<G32>(a, K, s);
+        case 256: return (long)((a.L + G256<11>::NT2 - 1) / G256<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G256S>(a, K, s) : launch_g_ks<G256>(a, K, s);
+        case 128: return (long)((a.L + G128<11>::NT2 - 1) / G128<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G128S>(a, K, s) : launch_g_ks<G128>(a, K, s);
+        case 64: return (long)((a.L + G64<11>::NT2 - 1) / G64<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G64S>(a, K, s) : launch_g_ks<G64>(a, K, s);
+        case 32: return (long)((a.L + G32<11>::NT2 - 1) / G32<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G32S>(a, K, s) : launch_g_ks<G32>(a, K, s);
     }
     return hipErrorInvalidValue;
 }
