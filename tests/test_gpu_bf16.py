@@ -108,15 +108,25 @@ def test_fused_pair_rejects_non_pair_keys(gen, dev):
             gen.run_pair(key, torch.zeros((1, 64, 256), device=dev))
 
 
+@pytest.mark.parametrize("L", [300, 1, 67], ids=lambda v: f"L{v}")
+@pytest.mark.parametrize("fuse", [3, 0], ids=["register-streamed", "first-generation"])
 @pytest.mark.parametrize("i", [0, 1, 2, 3])
-def test_upsample_kat_bf16(gen, v1_params, dev, i):
+def test_upsample_kat_bf16(gen, v1_params, dev, i, fuse, L):
+    """The transposed convolutions (model.py:88-94) on both kernel generations (fuse = 3: kernels_bf16_up.hip for all four;
+    fuse = 0: the 3-tap convolution of kernels_bf16.hip) against the zero-stuffed, un-flipped restatement on the same bf16
+    operands; L = 1: one frame (both neighbours are padding), 67: ragged against every tile width, 300: several tiles, and a
+    small launch (the register-streamed kernel then splits the output rows over several workgroups per tile)."""
     spec = [s for s in conv_specs(V1) if s.key == f"generator/~/ups_{i}"][0]
     rng = np.random.default_rng(40 + i)
-    B, L = 2, 300
+    B = 2
     x = rng.standard_normal((B, L, spec.cin)).astype(np.float32) * 2.0
     w, b = v1_params[spec.key]["w"], v1_params[spec.key]["b"]
     ref = orc.conv1d_transpose(bf(x), bf(w), b.astype(np.float64), spec.stride)
-    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 1.0).cpu().numpy()
+    gen.set_option("fuse", fuse)
+    try:
+        y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 1.0).cpu().numpy()
+    finally:
+        gen.set_option("fuse", 2)
     assert y.shape == (B, L * spec.stride, spec.cout)
     assert np.abs(y - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
 

@@ -77,6 +77,9 @@ struct Layer {
     // whole ResBlock (this layer = convs1_0 of a ResBlock with a fused kernel): six convolutions' fragments + six biases
     bool has_rb = false;
     size_t off_rw = 0, rw_bytes = 0, off_rb = 0;
+    // transposed convolution on the register-streamed kernel (kernels_bf16_up.hip): a second packing of the 3-tap form
+    bool has_ug = false;
+    size_t off_ug = 0, ug_bytes = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -162,6 +165,12 @@ int build_layers_bf16(vtts_hifigan* h) {
             l.wb_bytes = bf16_packed_bytes(g);
             l.off_wb = off;
             off = align_up(off + l.wb_bytes, 256);
+            if (l.kind == KIND_CONVT) {
+                l.has_ug = true;
+                l.ug_bytes = bf16_packed_bytes(convt_g_pack_geom(l.bcls));
+                l.off_ug = off;
+                off = align_up(off + l.ug_bytes, 256);
+            }
             if (l.kind == KIND_CONV && l.cin == l.cout) {
                 double fl = 0.0;
                 long len2 = 1;
@@ -431,7 +440,14 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
         }
         HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
     }
-    hipError_t e = launch_conv_bf16(l.bcls, K, a, s);
+    // transposed convolutions: the register-streamed kernel where it is the faster one (fuse >= 1; fuse = 3: everywhere), else the
+    // first-generation 3-tap convolution.  Per launch at B = 64 x T = 1024 (rocprofv3, profiles/r02_b_*): ups_0 329 vs 422 us,
+    // ups_1 575 vs 985, ups_2 684 vs 687, ups_3 597 vs 455 — the two HBM-bound ones (128 -> 2 x 64, 64 -> 2 x 32) keep the old
+    // kernel, whose epilogue goes through LDS and stores whole rows (the new one stores 32 bytes per frame and instruction).
+    const bool ug_pref = l.bcls == BCLS_UP0 || l.bcls == BCLS_UP1 || h->opt_fuse >= 3;
+    const bool ug = l.kind == KIND_CONVT && l.has_ug && h->opt_fuse >= 1 && ug_pref && res == nullptr && acc_add == 0 && div == 1.0f;
+    if (ug) a.wp = h->blob + l.off_ug;
+    hipError_t e = ug ? launch_convt_g_bf16(l.bcls, a, s) : launch_conv_bf16(l.bcls, K, a, s);
     if (prof) {
         HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
         h->prof_used++;
@@ -960,6 +976,7 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
                     }
                 }
                 bf16_pack(wc.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
+                if (l.has_ug) bf16_pack(wc.data(), l.cin, convt_g_pack_geom(l.bcls), reinterpret_cast<unsigned short*>(host.data() + l.off_ug));
             } else {
                 bf16_pack(l.w.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
             }

@@ -113,6 +113,11 @@ bool resblock_bf16_supported(int C, int K, const int* dils);
 bool resblock_bf16_preferred(int C, int K);
 hipError_t launch_resblock_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 const char* resblock_kernel_name(int C, int K);
+// the four transposed convolutions on the register-streamed structure (kernels_bf16_up.hip): cls = BCLS_UP0..3,
+// a.wp = the 3-tap polyphase form's weights packed with convt_g_pack_geom(cls) (bf16_pack)
+hipError_t launch_convt_g_bf16(int cls, const BConvArgs& a, hipStream_t s);
+BPackGeom convt_g_pack_geom(int cls);
+const char* convt_g_kernel_name(int cls);
 hipError_t launch_conv_post_bf16(const BConvArgs& a, float* wav, float* pre_act, hipStream_t s);
 hipError_t launch_bf16_to_f32(const void* in, float* out, size_t n, hipStream_t s);
 hipError_t launch_f32_to_bf16(const float* in, void* out, size_t n, hipStream_t s);
