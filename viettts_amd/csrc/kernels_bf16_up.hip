@@ -72,7 +72,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     {
         const float sin_ = a.slope_in;
         auto act2 = [&](unsigned u) { return sin_ == 1.0f ? u : lrelu_bf16x2(u, sin_); };
-        constexpr int XB = 4;  // loads in flight per thread: unconditional, from clamped addresses, masked afterwards
+        // every load of the tile in flight at once (nothing else is live yet; a batch of 4 per round trip left a 128 -> 2 x 64
+        // workgroup 10 us in staging for 2.5 us of MFMAs): unconditional, from clamped addresses, masked afterwards
+        constexpr int XB = XPT;
 #pragma unroll 1
         for (int i0 = 0; i0 < XPT; i0 += XB) {
             uint4 v[XB];
