@@ -27,6 +27,11 @@ class Generator:
 
     No CPU fallback: construction fails if the HIP extension is missing, and ``__call__`` fails
     unless the tensors live on a ROCm device.
+
+    Concurrency: one Generator serves ONE call at a time.  The C handle keeps per-call state (ragged lengths, profiling
+    counters, its side streams) and this object keeps one cached workspace tensor: two torch streams driving the same
+    Generator concurrently would race on both.  Use one Generator per stream (the packed weights can be shared:
+    ``other.adopt_packed(gen.packed_blob())``).
     """
 
     def __init__(self, cfg: HifiganConfig = V1, device="cuda:0", dtype: str = "f32", lib_path=None):

@@ -4,7 +4,8 @@ What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
   * ``load_lexicon`` / ``text2tokens`` — the deterministic text -> token-id front end (:16-19, :37-58);
   * the two INTEGER quantities BASELINE.json wants bit-exact — ``n_frames`` (:78-79) and the trailing
     ``silence_frame`` (:99-101) — as pure functions of the fp32 duration vector, computed with the
-    same dtype and operation order (fp32 multiply by 16000, fp32 divide by 256, fp32 sum, truncate);
+    same dtype and operations (fp32 multiply by 16000, fp32 divide by 256, fp32 sum, truncate; the order of the sum's
+    additions is numpy's, see :func:`n_frames_from_durations`);
   * ``text2mel(text, lexicon_fn, silence_duration)`` with the reference's signature.
 
   * ``predict_duration(tokens)`` (:22-34) on the MI355X: the NAT duration model (vietTTS/nat/model.py:9-70) runs in
@@ -87,7 +88,12 @@ def durations_to_frames(durations: np.ndarray) -> np.ndarray:
 
 
 def n_frames_from_durations(durations: np.ndarray) -> int:
-    """``int(jnp.sum(durations_in_frames).item())`` (text2mel.py:79): fp32 sum, truncation."""
+    """``int(jnp.sum(durations_in_frames).item())`` (text2mel.py:79): fp32 sum, truncation.
+
+    Exact in dtype, operand values and truncation.  The ORDER of the fp32 additions is numpy's (pairwise) here and XLA's in the
+    reference (unspecified, backend- and version-dependent): a sum that lands within an fp32 ulp of an integer can truncate
+    to a neighbouring frame count (one frame = 256 samples).  GPU vs oracle agree bit for bit (tests/test_gpu_nat.py: both use
+    this function on bit-identical durations); agreement with a JAX run is unverified (no jax offline)."""
     return int(np.sum(durations_to_frames(durations), dtype=np.float32))
 
 
