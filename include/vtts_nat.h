@@ -106,10 +106,21 @@ int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lma
  * Draws keep masks for forward() on the device: keep_dev [B, Fmax, 2, prenet_dim] bytes, P(keep) = 1/2 (hk.dropout(key,
  * 0.5, x), model.py:97,:99), from seeds_dev [B] (one 64-bit seed per sentence, so a sentence's masks do not depend on
  * the batch it is in) with Threefry-2x32-20: key = seed, counter = (2 * frame + layer, 64-column block), output bit j =
- * column 64 * block + j.  The cipher is the one jax.random uses; the STREAM is this library's own — the reference's
- * masks come from Haiku's per-scan-step splitting of the checkpoint's rng (text2mel.py:72-73), which is not restated.
+ * column 64 * block + j.  The cipher is the one jax.random uses; the STREAM is this library's own (per-sentence seeds:
+ * independent of batching, which a throughput pipeline wants) — the reference's own stream is the next entry point.
  */
 int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint64_t* seeds_dev, int B, int Fmax, uint8_t* keep_dev, void* stream);
+/*
+ * The same masks as the REFERENCE draws them (text2mel.py:65-73 -> model.py:95-100,134-142): (rng_key0, rng_key1) = the
+ * checkpoint's `rng` (a jax.random.PRNGKey, uint32[2]); dm-haiku's PRNGSequence hands out S_n of the chain
+ * (K_n, S_n) = jax.random.split(K_{n-1}), frame f takes S_{2f+1} and S_{2f+2}, a mask is
+ * jax.random.bernoulli(S, 0.5, (1, prenet_dim)) on jax.random's classic (pre-0.5 default, non-"partitionable") threefry
+ * layout.  Every sentence of the batch gets the same masks, as every run of the reference starts from the same key.
+ * Restatement: oracle/nat_oracle.py::haiku_prenet_keep_masks (pinned by the known answers JAX's documentation prints for
+ * PRNGKey(0); not by a JAX run: none is possible offline).  A checkpoint run under JAX >= 0.5 defaults draws another stream.
+ */
+int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int B, int Fmax, uint8_t* keep_dev,
+                                       void* stream);
 int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
                               const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
                               const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream);

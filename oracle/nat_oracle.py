@@ -263,3 +263,63 @@ def threefry_keep_masks(seed: int, n_frames: int, prenet_dim: int = 256) -> np.n
     x0, x1 = threefry2x32_20(np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF), ctr0, ctr1)
     bits = np.concatenate([(x0[:, None] >> np.arange(32, dtype=np.uint32)) & 1, (x1[:, None] >> np.arange(32, dtype=np.uint32)) & 1], axis=1)
     return bits.reshape(n_frames, 2, nblk * 64)[:, :, :prenet_dim].astype(bool)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's OWN mask stream (restated round 2): jax.random on the classic (non-partitionable) threefry implementation
+# — the default of every JAX release before 0.5 — under dm-haiku's PRNGSequence.  **Unpinned by a JAX run** (no jax
+# offline); pinned by the two known answers JAX's own documentation prints for PRNGKey(0) (tests/test_nat_cpu.py).
+#
+#   jax.random.split(key, 2)          counts = iota(uint32, 4); threefry_2x32 splits the counts into halves x0 = [0, 1],
+#       (jax/_src/prng.py)            x1 = [2, 3], enciphers the pairs (x0[i], x1[i]) with the key and concatenates the two
+#                                     output halves: new keys = [[y0[0], y0[1]], [y1[0], y1[1]]]
+#   jax.random.bits / uniform         counts = iota(uint32, n) (n = number of 32-bit words; an odd n is padded with one 0),
+#                                     halves as above; word i < n/2 = y0[i], word n/2 + i = y1[i]; uniform = bitcast(
+#                                     (word >> 9) | 0x3F800000) - 1.0
+#   jax.random.bernoulli(key, p, s)   uniform(key, s) < p
+#   hk.dropout(rng, rate, x)          keep = bernoulli(rng, 1 - rate, x.shape); keep * x / (1 - rate)      (haiku/_src/basic.py)
+#   hk.next_rng_key()                 PRNGSequence: (key, sub) = split(key, 2); key stays, sub is handed out — one split per
+#                                     call (reserve size 1).  hk.scan threads the sequence's state through the scan carry;
+#                                     releases that reserve a subkey before the scan and after every step consume the SAME
+#                                     chain of subkeys, only earlier.
+#   AcousticModel.inference           the only consumers are the prenet's two dropouts per frame (model.py:95-100,134-142;
+#                                     encoder and postnet draw nothing with is_training=False): with K_0 = the
+#                                     checkpoint's rng (text2mel.py:65-73) and (K_n, S_n) = split(K_{n-1}), frame t takes
+#                                     S_{2t+1} for the first mask and S_{2t+2} for the second, shape (1, 256): every
+#                                     sentence starts from the same K_0.
+# JAX >= 0.5 defaults to jax_threefry_partitionable=True (another counter layout for split and bits): a checkpoint run
+# there draws a different stream from the same key.  The reference pins no version (setup.py:6-19).
+# ---------------------------------------------------------------------------------------------------------------------
+def jax_legacy_threefry_2x32(key, counts):
+    """jax._src.prng.threefry_2x32 (classic layout): ``counts`` uint32 [n] -> uint32 [n]."""
+    counts = np.asarray(counts, dtype=np.uint32).ravel()
+    odd = counts.size % 2
+    if odd:
+        counts = np.concatenate([counts, np.zeros(1, np.uint32)])
+    half = counts.size // 2
+    y0, y1 = threefry2x32_20(np.uint32(key[0]), np.uint32(key[1]), counts[:half], counts[half:])
+    out = np.concatenate([y0, y1])
+    return out[:-1] if odd else out
+
+
+def jax_legacy_split(key, num: int = 2) -> np.ndarray:
+    """jax.random.split(key, num) -> uint32 [num, 2]."""
+    return jax_legacy_threefry_2x32(key, np.arange(2 * num, dtype=np.uint32)).reshape(num, 2)
+
+
+def jax_legacy_uniform(key, n: int) -> np.ndarray:
+    """jax.random.uniform(key, (n,), float32) in [0, 1)."""
+    bits = jax_legacy_threefry_2x32(key, np.arange(n, dtype=np.uint32))
+    return ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+
+
+def haiku_prenet_keep_masks(rng_key, n_frames: int, prenet_dim: int = 256) -> np.ndarray:
+    """``[n_frames, 2, prenet_dim]`` boolean keep masks of AcousticModel.inference's prenet dropout as the reference draws
+    them from ``rng_key`` (uint32 [2]: the checkpoint's ``rng``) — see the block comment above."""
+    key = np.asarray(rng_key, dtype=np.uint32).reshape(2)
+    out = np.empty((n_frames, 2, prenet_dim), dtype=bool)
+    for t in range(n_frames):
+        for layer in range(2):
+            key, sub = jax_legacy_split(key, 2)
+            out[t, layer] = jax_legacy_uniform(sub, prenet_dim) < np.float32(0.5)
+    return out

@@ -210,6 +210,29 @@ def test_device_keep_masks_equal_the_threefry_restatement(acoustic):
     assert np.array_equal(alone, got[2])
 
 
+def test_device_haiku_masks_equal_the_reference_stream_restatement(acoustic):
+    """vtts_nat_acoustic_keep_masks_haiku: the reference's own mask stream (checkpoint rng -> Haiku key chain -> jax.random
+    bernoulli on the classic threefry layout) drawn on the GPU == oracle/nat_oracle.py::haiku_prenet_keep_masks bit for bit,
+    the same for every sentence of the batch; and the acoustic model run with ``dropout_rng`` equals the oracle run on those masks."""
+    am, P, S = acoustic
+    for rng in ((0, 0), (123456789, 42), (0xFFFFFFFF, 0x80000001)):
+        got = am.device_keep_masks_haiku(rng, 3, 41).cpu().numpy()
+        want = no.haiku_prenet_keep_masks(np.array(rng, dtype=np.uint32), 41, 256)
+        assert got.shape == (3, 41, 2, 256) and got.dtype == np.uint8
+        for b in range(3):
+            assert np.array_equal(got[b].astype(bool), want), (rng, b)
+    rng = np.array([2024, 7], dtype=np.uint32)
+    toks = [[0, 5, 9, 3, 14, 22, 3, 0], [0, 31, 3, 0]]
+    frames = [np.array([3.0, 2.5, 4.0, 0.0, 3.5, 2.0, 0.0, 2.0], np.float32), np.array([2.0, 5.5, 0.0, 3.0], np.float32)]
+    nfr = [int(np.sum(f, dtype=np.float32)) for f in frames]
+    got = am(toks, frames, nfr, dropout_rng=rng)
+    masks = no.haiku_prenet_keep_masks(rng, max(nfr), 256)
+    for i in range(2):
+        want = no.acoustic_inference(P, S, np.array(toks[i]), frames[i], nfr[i], prenet_masks=lambda t: (masks[t, 0], masks[t, 1]), dtype=np.float64)
+        assert got[i].shape == want.shape
+        assert np.abs(got[i] - want).max() <= 5e-4 * max(1.0, np.abs(want).max()), i
+
+
 def test_acoustic_with_device_masks_matches_oracle(acoustic):
     """The product path: dropout seeds in, masks drawn on the GPU; the oracle gets the same masks from the restatement."""
     am, P, S = acoustic

@@ -156,3 +156,27 @@ def test_threefry_known_answers():
     assert m.shape == (40, 2, 256) and 0.47 < m.mean() < 0.53
     assert not np.array_equal(m, threefry_keep_masks(12346, 40, 256))
     assert np.array_equal(m[:10], threefry_keep_masks(12345, 10, 256))  # a frame's mask does not depend on the sentence's length
+
+
+def test_jax_legacy_prng_known_answers_and_haiku_mask_schedule():
+    """The reference's OWN mask stream (oracle/nat_oracle.py::haiku_prenet_keep_masks): jax.random's classic threefry layout,
+    pinned by the two values JAX's documentation prints for ``PRNGKey(0)`` — ``random.split(key)`` and ``random.uniform(key)``
+    (docs "Pseudo random numbers in JAX" / the jax.random module docstring) — on top of Random123's cipher vectors above."""
+    from oracle.nat_oracle import haiku_prenet_keep_masks, jax_legacy_split, jax_legacy_uniform
+
+    k0 = np.array([0, 0], dtype=np.uint32)  # jax.random.PRNGKey(0)
+    assert jax_legacy_split(k0).tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    u = jax_legacy_uniform(k0, 1)
+    assert u.dtype == np.float32 and abs(float(u[0]) - 0.41845703) < 5e-9
+    # odd / even word counts: the first words of a longer draw are NOT those of a shorter one (the counters are halved)
+    assert jax_legacy_uniform(k0, 4)[0] != jax_legacy_uniform(k0, 2)[0]
+    rng = np.array([123456789, 42], dtype=np.uint32)
+    m = haiku_prenet_keep_masks(rng, 30, 256)
+    assert m.shape == (30, 2, 256) and 0.47 < m.mean() < 0.53
+    assert np.array_equal(m[:7], haiku_prenet_keep_masks(rng, 7, 256))  # frame f's masks depend on the key chain up to f only
+    # the chain: frame 1's first mask comes from the subkey of the THIRD split
+    key = rng
+    for _ in range(3):
+        key, sub = jax_legacy_split(key, 2)
+    assert np.array_equal(m[1, 0], jax_legacy_uniform(sub, 256) < np.float32(0.5))
+    assert not np.array_equal(m[0, 0], m[0, 1])

@@ -17,7 +17,8 @@
 // skip connections on the fp32 matrix cores, cell update in registers; mel projection + next frame's prenet), then the
 // 5-layer postnet as fp32 MFMA convolutions.
 // The prenet's always-on dropout (model.py:95-100) takes explicit keep masks, which vtts_nat_acoustic_keep_masks can draw on
-// the device with jax.random's cipher (Threefry-2x32-20); Haiku's key-splitting schedule is not restated.
+// the device with jax.random's cipher (Threefry-2x32-20) from per-sentence seeds, and vtts_nat_acoustic_keep_masks_haiku as the
+// reference itself draws them from the checkpoint's rng (classic jax.random layout + Haiku's key chain, restated in round 2).
 #include "../../include/vtts_nat.h"
 
 #include <hip/hip_runtime.h>
@@ -688,6 +689,39 @@ __global__ void nat_keep_masks_k(const unsigned long long* __restrict__ seeds, u
     }
 }
 
+// The REFERENCE's mask stream (jax.random's classic threefry layout under dm-haiku's PRNGSequence; restated in
+// oracle/nat_oracle.py::haiku_prenet_keep_masks, which carries the derivation): K_0 = the checkpoint's rng,
+// (K_n, S_n) = jax.random.split(K_{n-1}) = the cipher on counters (0, 2) and (1, 3), frame f takes S_{2f+1} / S_{2f+2}, and a mask of
+// PN columns is uniform(S, (1, PN)) < 0.5: column c < half takes word x0 of counter (c, c + half), column half + c word x1
+// (half = ceil(PN / 2)); keep <=> the word's top bit is clear.  Every sentence of a batch gets the same masks (the reference runs
+// every sentence from the same checkpoint key).  One block per frame: its threads walk the key chain to frame f together (wave-
+// uniform, <= 4 * (f + 1) ciphers), then thread (layer, c) draws its word and writes it to all B sentences.
+__global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, unsigned char* __restrict__ keep, int B, int Fmax, int PN) {
+    const int f = blockIdx.x;
+    unsigned ka = k0, kb = k1, s0[2], s1[2];
+    for (int n = 0; n < 2 * f + 2; ++n) {
+        unsigned a0 = 0u, b0 = 2u, a1 = 1u, b1 = 3u;
+        threefry2x32_20(ka, kb, a0, b0);
+        threefry2x32_20(ka, kb, a1, b1);
+        ka = a0;  // split(key, 2)[0] = (y0[0], y0[1]) stays the sequence's key ...
+        kb = a1;
+        if (n >= 2 * f) {  // ... [1] = (y1[0], y1[1]) is handed out
+            s0[n - 2 * f] = b0;
+            s1[n - 2 * f] = b1;
+        }
+    }
+    const int half = (PN + 1) / 2;
+    for (int u = threadIdx.x; u < 2 * PN; u += blockDim.x) {
+        const int layer = u / PN, c = u % PN;
+        const int i = c < half ? c : c - half;
+        unsigned x0 = (unsigned)i, x1 = i + half < PN ? (unsigned)(i + half) : 0u;  // counters iota(PN) in two halves; an odd count is padded with one 0
+        threefry2x32_20(s0[layer], s1[layer], x0, x1);
+        const unsigned word = c < half ? x0 : x1;
+        const unsigned char kp = (word >> 31) ? 0 : 1;  // uniform = (word >> 9 | 1.0f) - 1 < 0.5  <=>  top bit clear
+        for (int b = 0; b < B; ++b) keep[(((size_t)b * Fmax + f) * 2 + layer) * PN + c] = kp;
+    }
+}
+
 // Frame 0's input: h1 = h2 = 0, c = 0 (memset), prenet(0) = 0 (no biases), cond_0 from the upsampler.
 __global__ void nat_dec_init_k(const float* __restrict__ cond, float* __restrict__ zcond, int B, int Bp, int Fmax, int E) {
     const int b = blockIdx.x;
@@ -1029,6 +1063,17 @@ VTTS_API int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint
     const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
     hipLaunchKernelGGL(nat_keep_masks_k, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const unsigned long long*>(seeds_dev),
                        keep_dev, B, Fmax, PN);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return failf(VTTS_ERR_HIP, "keep-mask launch failed: %s", hipGetErrorString(e));
+    return VTTS_OK;
+}
+VTTS_API int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int B, int Fmax, uint8_t* keep_dev,
+                                                void* stream) {
+    if (!h || !keep_dev) return failf(VTTS_ERR_INVALID, "null argument");
+    if (B <= 0 || Fmax <= 0) return failf(VTTS_ERR_INVALID, "B and Fmax must be positive (got %d, %d)", B, Fmax);
+    const int PN = h->cfg.prenet_dim;
+    hipLaunchKernelGGL(nat_keep_masks_haiku_k, dim3(Fmax), dim3(2 * PN < 1024 ? 2 * PN : 1024), 0, static_cast<hipStream_t>(stream), rng_key0, rng_key1, keep_dev,
+                       B, Fmax, PN);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return failf(VTTS_ERR_HIP, "keep-mask launch failed: %s", hipGetErrorString(e));
     return VTTS_OK;

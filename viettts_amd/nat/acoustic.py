@@ -113,11 +113,26 @@ class AcousticModel:
             _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks(self._h, _ptr(sd), B, int(Fmax), _ptr(keep), C.c_void_p(stream.cuda_stream)))
         return keep
 
+    def device_keep_masks_haiku(self, rng_key, B: int, Fmax: int) -> torch.Tensor:
+        """``[B, Fmax, 2, prenet_dim]`` uint8 keep masks as the REFERENCE draws them from the checkpoint's ``rng`` (a
+        jax.random.PRNGKey, uint32[2]): jax.random's classic threefry layout under dm-haiku's key chain (include/vtts_nat.h:
+        vtts_nat_acoustic_keep_masks_haiku; restated in oracle/nat_oracle.py::haiku_prenet_keep_masks).  The same masks for
+        every sentence, as every run of the reference starts from the same key."""
+        k = np.asarray(rng_key, dtype=np.uint32).reshape(2)
+        keep = torch.empty((int(B), int(Fmax), 2, self.prenet_dim), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks_haiku(self._h, int(k[0]), int(k[1]), int(B), int(Fmax), _ptr(keep),
+                                                                             C.c_void_p(stream.cuda_stream)))
+        return keep
+
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
-                 keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None, to_host: bool = True):
+                 keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None, to_host: bool = True,
+                 dropout_rng=None):
         """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``.
-        Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_seeds`` (one int per sentence: masks drawn on the
-        GPU), or neither (no dropout).  ``to_host=False`` returns the device tensor ``[B, Fmax, mel_dim]`` (rows past a
+        Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_rng`` (the checkpoint's jax PRNGKey, uint32[2]: the
+        reference's own mask stream, drawn on the GPU), or ``dropout_seeds`` (one int per sentence: this library's own
+        per-sentence streams, drawn on the GPU), or none of them (no dropout).  ``to_host=False`` returns the device tensor ``[B, Fmax, mel_dim]`` (rows past a
         sentence's ``n_frames`` are zero) instead of per-sentence host arrays: the generator's input stays in HBM."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
@@ -137,6 +152,8 @@ class AcousticModel:
             for i, m in enumerate(keep_masks):
                 keep[i, : n_frames[i]] = np.asarray(m, dtype=bool)[: n_frames[i]]
             keep_d = torch.from_numpy(keep).to(self.device)
+        elif dropout_rng is not None:
+            keep_d = self.device_keep_masks_haiku(dropout_rng, B, Fmax)
         elif dropout_seeds is not None:
             if len(dropout_seeds) != B:
                 raise ValueError("one dropout seed per sentence")

@@ -13,9 +13,10 @@ What is built (SURVEY.md §8b "companion entry", §8f rank 2 groundwork):
 
   * ``predict_mel(tokens, durations)`` (:61-82) on the MI355X: the acoustic network's inference path
     (vietTTS/nat/model.py:128-151) behind the same header (viettts_amd/nat/acoustic.py).  The reference's prenet
-    dropout is ON at inference and draws from JAX's threefry PRNG through Haiku's per-step splitting of the
-    checkpoint's key; that stream is not restated: ``predict_mel`` has the library draw its keep masks (rate 0.5) on
-    the GPU from ``dropout_seed`` (Threefry-2x32-20, include/vtts_nat.h) — statistically, not bitwise, the reference's mel.
+    dropout is ON at inference and draws from JAX's threefry PRNG through Haiku's key chain, starting from the
+    checkpoint's ``rng``: with a checkpoint loaded ``predict_mel`` draws THAT stream on the GPU (restated in round 2 for
+    jax.random's classic layout, pinned by JAX's documented known answers, not by a JAX run); without a key it draws this
+    library's own per-sentence stream from ``dropout_seed`` (Threefry-2x32-20, include/vtts_nat.h).
 
 ``text2mel`` uses a registered mel provider (:func:`set_mel_provider`; tests and the CLI's ``--mel-file``) if there is
 one, else the two networks, loading ``duration_latest_ckpt.pickle`` / ``acoustic_latest_ckpt.pickle`` from
@@ -149,33 +150,46 @@ def set_acoustic_model(model) -> None:
     _ACOUSTIC_MODEL = model
 
 
-def load_acoustic_checkpoint(path=None):
-    """``dic["params"], dic["aux"]`` of ``acoustic_latest_ckpt.pickle`` (text2mel.py:62-71)."""
+def load_acoustic_checkpoint(path=None, with_rng: bool = False):
+    """``dic["params"], dic["aux"]`` (and, ``with_rng``, ``dic["rng"]`` as uint32[2]) of ``acoustic_latest_ckpt.pickle``
+    (text2mel.py:62-71)."""
     import pickle
 
     path = FLAGS.ckpt_dir / "acoustic_latest_ckpt.pickle" if path is None else path
     with open(path, "rb") as f:
         dic = pickle.load(f)
     to_np = lambda d: {k: {n: np.asarray(a) for n, a in dict(v).items()} for k, v in dict(d).items()}
+    if with_rng:
+        rng = dic.get("rng")
+        return to_np(dic["params"]), to_np(dic["aux"]), (None if rng is None else np.asarray(rng).astype(np.uint32).reshape(-1)[-2:])
     return to_np(dic["params"]), to_np(dic["aux"])
 
 
-def predict_mel(tokens: Sequence[int], durations: np.ndarray, dropout_seed: Optional[int] = 0) -> np.ndarray:
+def predict_mel(tokens: Sequence[int], durations: np.ndarray, dropout_seed: Optional[int] = 0, dropout_rng=None) -> np.ndarray:
     """Reference signature and result (text2mel.py:61-82): ``durations`` float32 ``[1, L]`` in SECONDS -> mel
-    ``[1, n_frames, 80]`` with ``n_frames = int(sum(durations * sample_rate / hop))``.  ``dropout_seed=None`` turns the
-    prenet dropout off (deterministic; not what the reference does)."""
+    ``[1, n_frames, 80]`` with ``n_frames = int(sum(durations * sample_rate / hop))``.
+
+    Prenet dropout (always on in the reference, model.py:95-100): with ``dropout_rng`` (a jax PRNGKey, uint32[2]) — or, by
+    default, the ``rng`` of the checkpoint this function loaded, as text2mel.py:65-73 passes it to ``forward.apply`` — the
+    masks are the reference's own stream (jax.random's classic threefry layout under Haiku's key chain, drawn on the GPU);
+    without a key, ``dropout_seed`` seeds this library's own stream; ``dropout_seed=None`` and no key: no dropout."""
     global _ACOUSTIC_MODEL
     if _ACOUSTIC_MODEL is None:
         from .acoustic import AcousticModel
 
-        params, state = load_acoustic_checkpoint()
+        params, state, rng = load_acoustic_checkpoint(with_rng=True)
         m = AcousticModel()
         m.load_params(params, state)
+        m.checkpoint_rng = rng
         _ACOUSTIC_MODEL = m
+    if dropout_rng is None:
+        dropout_rng = getattr(_ACOUSTIC_MODEL, "checkpoint_rng", None)
     frames = durations_to_frames(durations)  # :78
     n_frames = n_frames_from_durations(durations)  # :79
     if n_frames < 1:
         return np.zeros((1, 0, FLAGS.mel_dim), dtype=np.float32)
+    if dropout_rng is not None:  # the reference's own stream
+        return _ACOUSTIC_MODEL([list(tokens)], [frames[0]], [n_frames], dropout_rng=dropout_rng)[0][None]
     seeds = None if dropout_seed is None else [dropout_seed]  # masks drawn on the GPU (include/vtts_nat.h)
     return _ACOUSTIC_MODEL([list(tokens)], [frames[0]], [n_frames], dropout_seeds=seeds)[0][None]
 
