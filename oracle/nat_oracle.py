@@ -25,8 +25,9 @@ published behaviour of the third-party modules the reference calls (dm-haiku / j
   layer 2's weight rows are ``[x ; h1 ; h2]``; the network output is ``concat`` of both layers' outputs
 * ``jax.nn.gelu`` default ``approximate=True`` (tanh form), ``jax.nn.softplus = logaddexp(x, 0)``
 * ``hk.dropout(key, rate, x)``: ``keep = bernoulli(key, 1 - rate)``; ``where(keep, x / (1 - rate), 0)``.  The keys
-  come from JAX's threefry PRNG through Haiku's per-scan-step splitting; that stream is NOT restated — callers pass
-  the keep masks explicitly (``prenet_masks``), so two implementations can be compared on identical masks.
+  come from JAX's threefry PRNG through Haiku's key chain; callers pass the keep masks explicitly (``prenet_masks``), so
+  two implementations can be compared on identical masks, and ``haiku_prenet_keep_masks`` (end of this file) restates the
+  reference's own stream for jax.random's classic layout.
 
 Only ``tests/`` may import this module.
 """

@@ -6,10 +6,12 @@ checkpoint's ``params`` / ``aux`` dicts.  All arithmetic happens in the HIP libr
 provides device memory and the stream.  There is no CPU path.
 
 The prenet's dropout is on at inference in the reference (model.py:95-100) and draws from JAX's threefry PRNG through
-Haiku's per-scan-step key splitting; that stream is not restated here.  ``keep_masks`` (boolean ``[n_frames, 2, 256]`` per
-sentence) makes the dropout explicit; ``dropout_seeds`` has the library draw the masks on the GPU (Threefry-2x32-20, one
-seed per sentence: the product path, nothing crosses PCIe); neither runs without dropout.  :func:`bernoulli_keep_masks`
-draws host masks from numpy's PCG64 for tests.  All of these are statistically, not bitwise, the reference's behaviour.
+Haiku's key chain, starting from the checkpoint's ``rng``.  ``dropout_rng`` (that key, uint32[2]) has the library draw THAT
+stream on the GPU (jax.random's classic threefry layout; restated in oracle/nat_oracle.py, pinned by JAX's documented
+``PRNGKey(0)`` answers, not by a JAX run); ``dropout_seeds`` draws this library's own per-sentence streams on the GPU (one
+seed per sentence, independent of batching: the throughput pipeline's choice); ``keep_masks`` (boolean
+``[n_frames, 2, 256]`` per sentence) makes the dropout explicit; none of them runs without dropout.
+:func:`bernoulli_keep_masks` draws host masks from numpy's PCG64 for tests.
 """
 from __future__ import annotations
 
