@@ -115,3 +115,36 @@ def test_gloo_world2_broadcast_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, True), (1, True, True)]
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with
+    N ranks on 127.0.0.1 (the driver's own launch line); with WORLD_SIZE set it does not, and a rank count that disagrees
+    with --gpus is an error (`--gpus 8` used to measure ONE GPU with a warning)."""
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["exe"], seen["argv"] = exe, list(argv)
+        raise SystemExit(0)
+
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert seen["exe"] == sys.executable and a[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in a and "--nproc-per-node=4" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert a[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and a[-7].endswith("bench.py")
+    # a launcher that started the wrong number of ranks is refused before any GPU work
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    seen.clear()
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert not seen and "WORLD_SIZE=1" in str(e.value)
