@@ -132,3 +132,22 @@ def test_normalize_and_tokens_bit_exact_vs_reference_functions():
             assert t2m.text2tokens(norm, lex) == c["tokens"], c["raw"]
             n_tok += len(c["tokens"])
     assert n_tok > 1900
+
+
+def test_frame_plan_equals_the_per_sentence_rules_bit_for_bit():
+    """viettts_amd.nat.text2mel.frame_plan (the pipeline's batched host step) against the per-sentence functions that mirror
+    text2mel.py:78-79, :90-102 — float32 frame vectors bit-identical, integer counts equal, on ragged random sentences."""
+    rng = np.random.default_rng(11)
+    toks, secs = [], []
+    for _ in range(300):
+        n = int(rng.integers(1, 140))
+        t = [0] + [int(v) for v in rng.choice([0, 3, 7, 19, 55, 90], size=n)] + ([0] if rng.random() < 0.7 else [9])
+        toks.append(t)
+        secs.append(np.abs(rng.normal(0.08, 0.05, size=len(t))).astype(np.float32))
+    for sd in (-1.0, 0.05, 0.2):
+        frames, nfr, trail = t2m.frame_plan(toks, secs, sd)
+        for i, (t, s) in enumerate(zip(toks, secs)):
+            d = t2m.apply_duration_rules(t, s[None, :], sd)
+            assert np.array_equal(frames[i], t2m.durations_to_frames(d)[0]) and frames[i].dtype == np.float32
+            assert nfr[i] == t2m.n_frames_from_durations(d)
+            assert trail[i] == (t2m.trailing_silence_frames(d) if t[-1] == FLAGS.sil_index else 0)

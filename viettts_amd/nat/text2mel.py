@@ -105,6 +105,36 @@ def trailing_silence_frames(durations: np.ndarray) -> int:
     return int(end_silence * FLAGS.sample_rate / (FLAGS.n_fft // 4))
 
 
+def frame_plan(token_lists, seconds, silence_duration: float):
+    """The frame rules of text2mel.py:78-79, :90-102 for MANY sentences at once (viettts_amd/pipeline.py): per sentence the
+    per-token durations in frames (float32), ``n_frames`` and the trailing-silence frame count — bit for bit what
+    :func:`apply_duration_rules` / :func:`durations_to_frames` / :func:`n_frames_from_durations` /
+    :func:`trailing_silence_frames` give sentence by sentence (tests/test_frontend_cpu.py).  The elementwise rules run once on a
+    padded ``[B, Lmax]`` array; the float32 sum of a sentence is taken over ITS tokens only (the additions' order depends on
+    the count)."""
+    B = len(token_lists)
+    lens = [len(t) for t in token_lists]
+    Lmax = max(lens) if B else 0
+    tok = np.full((B, Lmax), -1, dtype=np.int64)
+    d = np.zeros((B, Lmax), dtype=np.float32)
+    for i, (t, s) in enumerate(zip(token_lists, seconds)):
+        tok[i, : lens[i]] = t
+        d[i, : lens[i]] = np.asarray(s, dtype=np.float32).reshape(-1)
+    d = np.where(tok == FLAGS.sil_index, np.maximum(d, np.float32(silence_duration)), d).astype(np.float32)
+    d = np.where(tok == FLAGS.word_end_index, np.float32(0.0), d).astype(np.float32)
+    fr = (d * np.float32(FRAMES_PER_SECOND_NUM)) / np.float32(FRAMES_PER_SECOND_DEN)
+    frames, nfr, trail = [], [], []
+    for i in range(B):
+        row = fr[i, : lens[i]]
+        frames.append(row)
+        nfr.append(int(np.sum(row[None, :], dtype=np.float32)))
+        if lens[i] and tok[i, lens[i] - 1] == FLAGS.sil_index:
+            trail.append(int(float(d[i, lens[i] - 1]) * FLAGS.sample_rate / (FLAGS.n_fft // 4)))
+        else:
+            trail.append(0)
+    return frames, nfr, trail
+
+
 _DURATION_MODEL = None
 
 

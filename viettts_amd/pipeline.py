@@ -46,12 +46,7 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     toks = [list(token_lists[i]) for i in mine]
     secs = duration_model(toks)  # [L] seconds per token each
     t_last = mark("duration_s", t_last)
-    frames, nfr, trail = [], [], []
-    for t, d in zip(toks, secs):
-        d = t2m.apply_duration_rules(t, d[None, :], silence_duration)  # text2mel.py:90-97
-        frames.append(t2m.durations_to_frames(d)[0])  # :78
-        nfr.append(t2m.n_frames_from_durations(d))  # :79
-        trail.append(t2m.trailing_silence_frames(d) if t[-1] == FLAGS.sil_index else 0)  # :99-101
+    frames, nfr, trail = t2m.frame_plan(toks, secs, silence_duration)  # text2mel.py:78-79, :90-102 for the whole shard at once
     ok = [k for k, n in enumerate(nfr) if n >= 1]
     t_last = mark("host_rules_s", t_last)
     wavs: Dict[int, np.ndarray] = {}
