@@ -484,7 +484,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #endif
 template <int KS> using G128 = GTile<128, KS, KS == 3 ? VTTS_G128K3_N1 : 256, 2, 2, 3, KS == 3 ? VTTS_G128K3_WG : 2>;
 template <int KS> using G64 = GTile<64, KS, VTTS_G64_N1, 1, 4, 3, VTTS_G64_WG>;
-template <int KS> using G32 = GTile<32, KS, VTTS_G32_N1, 1, 4, 3, VTTS_G32_WG>;
+#ifndef VTTS_G32_PA
+#define VTTS_G32_PA 3
+#endif
+template <int KS> using G32 = GTile<32, KS, VTTS_G32_N1, 1, 4, VTTS_G32_PA, VTTS_G32_WG>;
 template <int KS> using G256 = GTile<256, KS, 128, 4, 1, 3, 2, 128>;
 // narrow tiles for SMALL launches (batch-1 latency: a 512-frame utterance is 35 wide tiles at C = 256, 134 at C = 128 — a
 // fraction of the 512 workgroup slots): half the time steps per workgroup, twice the workgroups.  Same per-element
