@@ -112,7 +112,26 @@ struct NatModel {
         for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
             add(te + l, "w", {2 * D, 4 * D});
             add(te + l, "b", {4 * D});
+            add_lstm_mfma(te + l, 2 * D, D);  // rows [x ; h] as hk.LSTM concatenates them
         }
+    }
+    // an hk.LSTM's [K][4H] matrix in MFMA A-fragment order for nat_dec_lstm_k: [slice = 8 units][K/8][lane][4],
+    // element i of lane = W[hrow(8*kb + 4*(lane/32) + i)][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4);
+    // hrow maps a row of the kernel's state order to the row of the Haiku matrix (identity unless the caller permutes)
+    void add_lstm_mfma(const std::string& mod, int K, int H, std::function<int(int)> hrow = nullptr) {
+        add_extra(mod + "#mfma", (size_t)K * 4 * H * sizeof(float), [mod, K, H, hrow](const NatModel& m, float* out) {
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            const int NIT = K / 8;
+            for (int sl = 0; sl < H / 8; ++sl)
+                for (int kb = 0; kb < NIT; ++kb)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
+                        for (int i = 0; i < 4; ++i) {
+                            const int zr = 8 * kb + 4 * lh + i;
+                            out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)(hrow ? hrow(zr) : zr) * 4 * H + col];
+                        }
+                    }
+        });
     }
     void add_extra(const std::string& key, size_t bytes, std::function<void(const NatModel&, float*)> fill) {
         Extra e;
@@ -397,45 +416,6 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
         }
 }
 
-// hk.LSTM over one sentence in one direction (model.py:39-45).  grid = (B, 2); blockDim = 4*D (one thread per gate
-// column, order i, g, f, o; forget gate +1).  w [2D][4D] (rows: x then h), b [4D].  out[b][t][dir*D + j] = h_t[j]; the
-// backward direction walks t = len-1 .. 0 and stores at t, which IS jnp.flip of its outputs (:46).  hk.ResetCore's
-// reset falls on the backward pass's first step(s), where the state still is the initial state.
-__global__ __launch_bounds__(1024) void nat_lstm_k(const float* __restrict__ x, const int* __restrict__ lengths, const float* __restrict__ wf,
-                                                   const float* __restrict__ bf, const float* __restrict__ wb, const float* __restrict__ bb,
-                                                   float* __restrict__ out, int Lmax, int D) {
-    extern __shared__ float sm[];  // xh[2D], gates[4D]
-    float* xh = sm;
-    float* gates = sm + 2 * D;
-    const int b = blockIdx.x, dir = blockIdx.y;
-    const int g = threadIdx.x;  // gate column
-    const int len = lengths[b];
-    const float* __restrict__ w = dir ? wb : wf;
-    const float bias = (dir ? bb : bf)[g];
-    float c = 0.0f;
-    if (g < D) xh[D + g] = 0.0f;
-    for (int s = 0; s < len; ++s) {
-        const int t = dir ? len - 1 - s : s;
-        if (g < D) xh[g] = x[((size_t)b * Lmax + t) * D + g];
-        __syncthreads();
-        float acc = bias;
-        const float* __restrict__ wc = w + g;
-        const int W4 = 4 * D;
-#pragma unroll 8
-        for (int k = 0; k < 2 * D; ++k) acc = fmaf(xh[k], wc[(size_t)k * W4], acc);
-        gates[g] = acc;
-        __syncthreads();
-        if (g < D) {
-            const float gi = gates[g], gg = gates[D + g], gf = gates[2 * D + g], go = gates[3 * D + g];
-            c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
-            const float h = sigmoidf_(go) * tanhf(c);
-            xh[D + g] = h;
-            out[((size_t)b * Lmax + t) * (2 * D) + dir * D + g] = h;
-        }
-        // the next step's barrier orders these writes before the next reads of xh[D..] / gates
-    }
-}
-
 // durations = softplus(Linear(D->1)(gelu(Linear(2D->D)(enc))))   (model.py:64-70); blockDim = D, one token per block
 __global__ void nat_duration_head_k(const float* __restrict__ enc, const int* __restrict__ lengths, const float* __restrict__ w1,
                                     const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
@@ -549,13 +529,28 @@ constexpr int NAT_DEC_PD = 4;   // iterations (8 k each) a wave keeps in flight 
 
 // NT = 32-sentence tiles per wave (one weight fragment feeds NT MFMAs: L2 traffic for the weights / NT), KW = waves per
 // workgroup, each with a contiguous share of K; their partial sums meet in LDS in a fixed tree order.
+// One LSTM's operands; blockIdx.z picks one of two sets (the token encoder steps its forward and backward LSTMs in one launch).
+struct NatLstmOps {
+    const float* inA;    // KA state rows, then
+    const float* inB;    // KB state rows (the LSTM's own previous hidden state)
+    const float4* wpk;   // [slice][K/8][lane][4]
+    const float* bias;   // [4H], gates i, g, f, o
+    float* cst;          // cell state [H][Bp]
+    float* hout;         // new hidden state, state layout
+};
 template <int NT, int KW>
-__global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restrict__ inA, int KA, const float* __restrict__ inB, int KB,
-                                                          const float4* __restrict__ wpk, const float* __restrict__ bias, float* __restrict__ cst,
-                                                          float* __restrict__ hout, const int* __restrict__ nframes, int f, int B, int Bp, int H) {
+__global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLstmOps ops1, int KA, int KB, const int* __restrict__ nframes, int f, int B,
+                                                          int Bp, int H) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     static_assert(KW == 1 || KW == 2 || KW == 4 || KW == 8, "tree reduction");
     __shared__ float red[KW > 1 ? KW / 2 : 1][NT][16][64];
+    const NatLstmOps& ops = blockIdx.z ? ops1 : ops0;
+    const float* __restrict__ inA = ops.inA;
+    const float* __restrict__ inB = ops.inB;
+    const float4* __restrict__ wpk = ops.wpk;
+    const float* __restrict__ bias = ops.bias;
+    float* __restrict__ cst = ops.cst;
+    float* __restrict__ hout = ops.hout;
     const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
     const int slice = blockIdx.x, b0 = blockIdx.y * 32 * NT;
     bool live[NT];
@@ -648,6 +643,43 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(const float* __restric
             cst[(size_t)u * Bp + b] = c;
             hout[nat_zidx(u, b, Bp)] = sigmoidf_(go) * tanhf(c);
         }
+    }
+}
+
+// TokenEncoder's two LSTMs (model.py:39-46) on the same batched step kernel: hk.LSTM over [x_t ; h] is the decoder step with
+// KA = D input rows and KB = D hidden rows, and all sentences advance together (one launch per token position steps BOTH
+// directions: blockIdx.z).  The step kernel wants its operands k-major with the sentences contiguous, so
+//   nat_enc_scatter_k : x [B][Lmax][D] -> XT[dir][s][D/4][Bp][4]; step s of the backward LSTM reads token len-1-s, which IS
+//                       hk.dynamic_unroll over the length-reversed sequence (jnp.flip with the ResetCore reset falling on the
+//                       padding steps, where the state still is the initial state);
+//   step s            : reads XT[dir][s] and HS[dir][s] (slab 0 = zeros = the initial state), writes HS[dir][s + 1] for the
+//                       sentences with s < len (the others' columns are never read again);
+//   nat_enc_gather_k  : enc[b][t][dir * D + j] = HS[dir][1 + (dir ? len-1-t : t)][j][b], zero at and beyond the length.
+__global__ __launch_bounds__(256) void nat_enc_scatter_k(const float* __restrict__ x, const int* __restrict__ lengths, float* __restrict__ xt, int B, int Bp,
+                                                         int Lmax, int D) {
+    const int s = blockIdx.x, dir = blockIdx.z, D4 = D / 4;
+    const size_t slab = (size_t)D * Bp;
+    float4* __restrict__ dst = reinterpret_cast<float4*>(xt + ((size_t)dir * Lmax + s) * slab);
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < D4 * Bp; i += gridDim.y * 256) {
+        const int k4 = i / Bp, b = i - k4 * Bp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) {
+            const int len = lengths[b];
+            if (s < len) v = *reinterpret_cast<const float4*>(x + ((size_t)b * Lmax + (dir ? len - 1 - s : s)) * D + 4 * k4);
+        }
+        dst[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void nat_enc_gather_k(const float* __restrict__ hs, const int* __restrict__ lengths, float* __restrict__ enc, int Bp,
+                                                        int Lmax, int D) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const int len = lengths[b];
+    const size_t slab = (size_t)D * Bp;
+    for (int c = threadIdx.x; c < 2 * D; c += 256) {
+        const int dir = c >= D, j = c - dir * D;
+        float v = 0.0f;
+        if (t < len) v = hs[((size_t)dir * (Lmax + 1) + 1 + (dir ? len - 1 - t : t)) * slab + nat_zidx(j, b, Bp)];
+        enc[((size_t)b * Lmax + t) * 2 * D + c] = v;
     }
 }
 
@@ -827,8 +859,13 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
 }
 
 // ---- shared host-side sequence: TokenEncoder of `m` under module prefix `te` -> enc [B][Lmax][2D] ------------------
+// scratch of the two encoder LSTMs: XT[2][Lmax], HS[2][Lmax + 1] slabs of [D][Bp] and the two cell states
+size_t nat_enc_lstm_floats(int D, int B, int Lmax) {
+    const size_t Bp = (size_t)(B + 63) / 64 * 64;
+    return ((size_t)2 * Lmax + 2 * ((size_t)Lmax + 1) + 2) * D * Bp;
+}
 int run_token_encoder(const NatModel& m, const std::string& te, int V, int D, const int32_t* tokens, const int32_t* lengths, int B, int Lmax,
-                      float* bufA, float* bufB, float* enc, hipStream_t s) {
+                      float* bufA, float* bufB, float* lstm_ws, float* enc, hipStream_t s) {
     hipLaunchKernelGGL(nat_embed_k, dim3(Lmax, B), dim3(256), 0, s, tokens, lengths, m.dev(te + "embed", "embeddings"), bufA, Lmax, D, V);
     constexpr int TL = 8;
     float* cur = bufA;
@@ -841,8 +878,37 @@ int run_token_encoder(const NatModel& m, const std::string& te, int V, int D, co
                            D, D, (int)NAT_ACT_RELU);
         std::swap(cur, nxt);
     }
-    hipLaunchKernelGGL(nat_lstm_k, dim3(B, 2), dim3(4 * D), 6 * D * sizeof(float), s, cur, lengths, m.dev(te + "lstm/linear", "w"),
-                       m.dev(te + "lstm/linear", "b"), m.dev(te + "lstm_1/linear", "w"), m.dev(te + "lstm_1/linear", "b"), enc, Lmax, D);
+    {  // forward + backward hk.LSTM (model.py:39-46), every sentence and both directions per launch
+        const int Bp = (B + 63) / 64 * 64;
+        const size_t slab = (size_t)D * Bp;
+        float* xt = lstm_ws;                                   // [2][Lmax] slabs
+        float* hs = xt + 2 * (size_t)Lmax * slab;              // [2][Lmax + 1] slabs
+        float* cs = hs + 2 * ((size_t)Lmax + 1) * slab;        // [2] slabs
+        HIP_TRYN(hipMemsetAsync(hs, 0, slab * 4, s));
+        HIP_TRYN(hipMemsetAsync(hs + ((size_t)Lmax + 1) * slab, 0, slab * 4, s));
+        HIP_TRYN(hipMemsetAsync(cs, 0, 2 * slab * 4, s));
+        const int gy = (int)std::min<size_t>((slab / 4 + 255) / 256, 64);
+        hipLaunchKernelGGL(nat_enc_scatter_k, dim3(Lmax, gy, 2), dim3(256), 0, s, cur, lengths, xt, B, Bp, Lmax, D);
+        const bool wide = B > 32;  // two 32-sentence tiles per wave once there are that many sentences
+        const dim3 lgrid(D / 8, wide ? Bp / 64 : 1, 2);
+        NatLstmOps o[2];
+        for (int dir = 0; dir < 2; ++dir) {
+            const std::string mod = te + (dir ? "lstm_1/linear" : "lstm/linear");
+            o[dir].wpk = reinterpret_cast<const float4*>(m.extra(mod + "#mfma"));
+            o[dir].bias = m.dev(mod, "b");
+            o[dir].cst = cs + dir * slab;
+        }
+        for (int st = 0; st < Lmax; ++st) {
+            for (int dir = 0; dir < 2; ++dir) {
+                o[dir].inA = xt + ((size_t)dir * Lmax + st) * slab;
+                o[dir].inB = hs + ((size_t)dir * (Lmax + 1) + st) * slab;
+                o[dir].hout = hs + ((size_t)dir * (Lmax + 1) + st + 1) * slab;
+            }
+            if (wide) hipLaunchKernelGGL((nat_dec_lstm_k<2, 8>), lgrid, dim3(512), 0, s, o[0], o[1], D, D, lengths, st, B, Bp, D);
+            else hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, o[0], o[1], D, D, lengths, st, B, Bp, D);
+        }
+        hipLaunchKernelGGL(nat_enc_gather_k, dim3(Lmax, B), dim3(256), 0, s, hs, lengths, enc, Bp, Lmax, D);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return failf(VTTS_ERR_HIP, "token encoder launch failed: %s", hipGetErrorString(e));
     return VTTS_OK;
@@ -850,7 +916,7 @@ int run_token_encoder(const NatModel& m, const std::string& te, int V, int D, co
 
 int check_encoder_dims(const char* what, int D, int V) {
     if (D < 64 || D > 256 || D % 64 != 0 || V < 1)
-        return failf(VTTS_ERR_INVALID, "%s: encoder width must be 64, 128, 192 or 256 (one thread per gate column, 4*width <= 1024) and vocab_size >= 1 (got %d, %d)",
+        return failf(VTTS_ERR_INVALID, "%s: encoder width must be 64, 128, 192 or 256 (one thread per channel in the convolutions) and vocab_size >= 1 (got %d, %d)",
                      what, D, V);
     return VTTS_OK;
 }
@@ -907,8 +973,8 @@ VTTS_API int vtts_nat_duration_workspace_bytes(const vtts_nat_duration* h, int B
     if (!h || !bytes) return failf(VTTS_ERR_INVALID, "null argument");
     if (B <= 0 || Lmax <= 0) return failf(VTTS_ERR_INVALID, "B and Lmax must be positive (got %d, %d)", B, Lmax);
     const size_t D = h->cfg.lstm_dim;
-    // two ping-pong [B][Lmax][D] buffers + the encoder output [B][Lmax][2D]
-    *bytes = 2 * align_up((size_t)B * Lmax * D * 4, 256) + align_up((size_t)B * Lmax * 2 * D * 4, 256);
+    // two ping-pong [B][Lmax][D] buffers + the encoder output [B][Lmax][2D] + the LSTMs' scratch
+    *bytes = 2 * align_up((size_t)B * Lmax * D * 4, 256) + align_up((size_t)B * Lmax * 2 * D * 4, 256) + align_up(nat_enc_lstm_floats((int)D, B, Lmax) * 4, 256);
     return VTTS_OK;
 }
 VTTS_API int vtts_nat_duration_forward(vtts_nat_duration* h, const int32_t* tokens_dev, const int32_t* lengths_dev, int B, int Lmax,
@@ -925,7 +991,8 @@ VTTS_API int vtts_nat_duration_forward(vtts_nat_duration* h, const int32_t* toke
     float* bufA = reinterpret_cast<float*>(static_cast<char*>(workspace));
     float* bufB = reinterpret_cast<float*>(static_cast<char*>(workspace) + per);
     float* enc = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * per);
-    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, enc, s);
+    float* lstm_ws = reinterpret_cast<float*>(static_cast<char*>(workspace) + 2 * per + align_up((size_t)B * Lmax * 2 * D * 4, 256));
+    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);
     if (rc) return rc;
     hipLaunchKernelGGL(nat_duration_head_k, dim3(Lmax, B), dim3(D), (2 * D + 16) * sizeof(float), s, enc, lengths_dev, h->dev("linear", "w"),
                        h->dev("linear", "b"), h->dev("linear_1", "w"), h->dev("linear_1", "b"), durations_dev, Lmax, D);
@@ -990,25 +1057,10 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
                 for (int c = 0; c < cols; ++c) out[((size_t)(k >> 2) * cols + c) * 4 + (k & 3)] = W[(size_t)k * cols + c];
         });
     }
-    // decoder LSTM weights in MFMA A-fragment order (nat_dec_lstm_k): [slice = 8 units][K/8][lane][4],
-    // element i of lane = W[hrow(8*kb + 4*(lane/32) + i)][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4);
-    // hrow maps a row of the decoder STATE ([h1 | x | h2] for layer 2) to the row of the Haiku matrix ([x | h1 | h2]).
-    for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
-        const std::string mod = l;
-        const bool skip = mod == "lstm_1/linear";
-        const int K = skip ? X + H + H : X + H;
-        h->add_extra(mod + "#mfma", (size_t)K * 4 * H * sizeof(float), [mod, K, H, X, skip](const NatModel& m, float* out) {
-            auto hrow = [=](int zr) { return !skip ? zr : (zr < H ? X + zr : (zr < H + X ? zr - H : zr)); };
-            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
-            const int NIT = K / 8;
-            for (int sl = 0; sl < H / 8; ++sl)
-                for (int kb = 0; kb < NIT; ++kb)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
-                        for (int i = 0; i < 4; ++i) out[(((size_t)sl * NIT + kb) * 64 + lane) * 4 + i] = W[(size_t)hrow(8 * kb + 4 * lh + i) * 4 * H + col];
-                    }
-        });
-    }
+    // decoder LSTM weights in the step kernel's order (add_lstm_mfma); layer 2's Haiku matrix is [x | h1 | h2] and the decoder
+    // STATE holds [h1 | x | h2], so its rows are permuted here
+    h->add_lstm_mfma("lstm/linear", X + H, H);
+    h->add_lstm_mfma("lstm_1/linear", X + H + H, H, [H, X](int zr) { return zr < H ? X + zr : (zr < H + X ? zr - H : zr); });
     h->layout();
     *out = h;
     return VTTS_OK;
@@ -1052,7 +1104,8 @@ VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B
              + align_up((size_t)B * Fmax * 2 * D * 4, 256)                                                 // cond
              + align_up((size_t)B * Fmax * MEL * 4, 256)                                                   // decoder mel
              + 2 * align_up((size_t)B * Fmax * PD * 4, 256)                                                // postnet ping-pong
-             + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256);                                         // decoder state Z[2], c1, c2
+             + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256)                                          // decoder state Z[2], c1, c2
+             + align_up(nat_enc_lstm_floats((int)D, B, Lmax) * 4, 256);                                    // encoder LSTMs' scratch
     return VTTS_OK;
 }
 VTTS_API int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint64_t* seeds_dev, int B, int Fmax, uint8_t* keep_dev, void* stream) {
@@ -1105,7 +1158,8 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
     float* pA = take((size_t)B * Fmax * PD * 4);
     float* pB = take((size_t)B * Fmax * PD * 4);
     float* dstate = take(nat_dec_state_floats(h->cfg, B) * 4);
-    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, enc, s);  // model.py:131
+    float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);
+    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);  // model.py:131
     if (rc) return rc;
     hipLaunchKernelGGL(nat_upsample_k, dim3(Fmax, B), dim3(256), (2 * Lmax + 8) * sizeof(float), s, enc, lengths_dev, durations_dev, nframes_dev, cond,
                        Lmax, Fmax, E);  // :132
@@ -1127,10 +1181,9 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
         const bool wide = B > 32;  // two 32-sentence tiles per wave once there are that many sentences
         const dim3 lgrid(H / 8, wide ? Bp / 64 : 1);
         auto lstm = [&](const float* inA, int KA, const float* inB, const float4* w, const float* bias, float* cst, float* hout, int f) {
-            if (wide)
-                hipLaunchKernelGGL((nat_dec_lstm_k<2, 8>), lgrid, dim3(512), 0, s, inA, KA, inB, H, w, bias, cst, hout, nframes_dev, f, B, Bp, H);
-            else
-                hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, inA, KA, inB, H, w, bias, cst, hout, nframes_dev, f, B, Bp, H);
+            const NatLstmOps o{inA, inB, w, bias, cst, hout};
+            if (wide) hipLaunchKernelGGL((nat_dec_lstm_k<2, 8>), lgrid, dim3(512), 0, s, o, o, KA, H, nframes_dev, f, B, Bp, H);
+            else hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, o, o, KA, H, nframes_dev, f, B, Bp, H);
         };
         const size_t plds = ((size_t)2 * H + 1024 + MEL + PN) * sizeof(float4);
         for (int f = 0; f < Fmax; ++f) {
