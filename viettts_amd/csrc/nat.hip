@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256) void nat_enc_gather_k(const float* __restrict_
 // Keep masks for the prenet's dropout drawn on the device: Threefry-2x32 with 20 rounds (Salmon et al., SC'11 — the
 // block cipher jax.random is built on), key = the sentence's 64-bit seed, counter = (2 * frame + layer, 64-column block);
 // the 64 output bits are the keep flags of 64 consecutive prenet columns (P(keep) = 1/2 = 1 - rate, model.py:97,99).
-// This is a stream of our own: Haiku's per-scan-step key splitting is not restated (include/vtts_nat.h).
+// This is a stream of our own (one seed per sentence, for batches of unrelated sentences); the reference's schedule from the
+// checkpoint's rng is nat_keep_masks_haiku_k below.
 __device__ __forceinline__ void threefry2x32_20(unsigned k0, unsigned k1, unsigned& x0, unsigned& x1) {
     const unsigned ks[3] = {k0, k1, 0x1BD11BDAu ^ k0 ^ k1};
     const int R[8] = {13, 15, 26, 6, 17, 29, 16, 24};
