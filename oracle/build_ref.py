@@ -18,7 +18,6 @@ Usage:  python oracle/build_ref.py        (no-op with a message when /root/refer
 """
 from __future__ import annotations
 
-import contextlib
 import io
 import json
 import sys

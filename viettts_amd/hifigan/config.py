@@ -9,9 +9,9 @@ Mirrors what the reference reads at the boundary:
 from __future__ import annotations
 
 import json
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from pathlib import Path
-from typing import List, Sequence
+from typing import Sequence
 
 
 class FLAGS:

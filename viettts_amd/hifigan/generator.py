@@ -8,7 +8,7 @@ library (include/vtts_hifigan.h); PyTorch-ROCm only provides device memory and t
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Optional
+from typing import Optional
 
 import numpy as np
 import torch

@@ -18,7 +18,7 @@ mel shape raises ``ValueError``.
 from __future__ import annotations
 
 import os
-from typing import Optional, Tuple
+from typing import Optional
 
 import numpy as np
 import torch

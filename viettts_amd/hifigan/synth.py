@@ -22,7 +22,6 @@ from __future__ import annotations
 
 import hashlib
 import math
-from typing import Dict
 
 import numpy as np
 import torch

@@ -16,7 +16,7 @@ seed per sentence, independent of batching: the throughput pipeline's choice); `
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch

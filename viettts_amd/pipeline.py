@@ -11,14 +11,13 @@ gives every utterance the zero padding it would see alone and skips the tiles pa
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
 
 from .dist import shard_utterances
 from .nat import text2mel as t2m
-from .nat.config import FLAGS
 
 
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
