@@ -54,7 +54,6 @@ def main() -> int:
         return 0
     import warnings
 
-    import numpy as np
     import torch
 
     sys.path.insert(0, str(REPO))
