@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
     const int MB = (Cout + 31) / 32, NCS = (Cin + 31) / 32;
     const int mb0 = (blockIdx.y * 4 + wave) * MR;
     if (t0 >= len || mb0 >= MB) return;  // rows at or past the length: zero by the caller's memset (last layer) or masked by the reader
+    const bool two = len - t0 > 32;      // a sentence's last tile with <= 32 frames left: the second 32-frame block is skipped (uniform)
     f32x16 acc[MR][NR];
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
             }
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
+                if (nr == 1 && !two) continue;
                 const int t = t0 + nr * 32 + l31 + j - PL;
                 const int tc = t < 0 ? 0 : (t >= len ? len - 1 : t);  // unconditional loads from clamped addresses, masked afterwards
 #pragma unroll
@@ -361,19 +363,23 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].x, bv[nr][q].x, acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].x, bv[nr][q].x, acc[mr][nr], 0, 0, 0);
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].y, bv[nr][q].y, acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].y, bv[nr][q].y, acc[mr][nr], 0, 0, 0);
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].z, bv[nr][q].z, acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].z, bv[nr][q].z, acc[mr][nr], 0, 0, 0);
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].w, bv[nr][q].w, acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].w, bv[nr][q].w, acc[mr][nr], 0, 0, 0);
             }
         }
     }
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int t = t0 + nr * 32 + l31;
-                if (t >= Lmax) continue;
+                if (t >= Lmax || (nr == 1 && !two)) continue;
                 const size_t o = ((size_t)b * Lmax + t) * Cout + co;
                 float v[4];
 #pragma unroll
