@@ -46,7 +46,9 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     secs = duration_model(toks)  # [L] seconds per token each
     t_last = mark("duration_s", t_last)
     frames, nfr, trail = t2m.frame_plan(toks, secs, silence_duration)  # text2mel.py:78-79, :90-102 for the whole shard at once
-    ok = [k for k, n in enumerate(nfr) if n >= 1]
+    # longest first: the decoder steps all sentences together and a 64-sentence tile leaves the per-frame launches once ITS longest
+    # sentence is done, so tiles of similar lengths finish early (a sentence's mel does not depend on its row: rows are independent)
+    ok = sorted((k for k, n in enumerate(nfr) if n >= 1), key=lambda k: (-nfr[k], k))
     t_last = mark("host_rules_s", t_last)
     wavs: Dict[int, np.ndarray] = {}
     gfr = {k: nfr[k] - trail[k] for k in ok}  # frames the generator sees: the mel minus its trailing silence (:102)
