@@ -84,6 +84,9 @@ def test_error_paths(lib):
     assert lib.vtts_hifigan_set_option(h, b"bogus", 1) == -1
     n = C.c_size_t(0)
     assert lib.vtts_hifigan_workspace_bytes(h, 0, 4, C.byref(n)) == -1
+    # an utterance whose activations would overflow the kernels' 32-bit row * channel indexing is refused, not mis-indexed
+    big = (1 << 31) // (TINY.upsample_initial_channel // 2 * TINY.upsample_rates[0]) + 1
+    assert lib.vtts_hifigan_workspace_bytes(h, 1, big, C.byref(n)) == -1 and b"too long" in lib.vtts_last_error()
     lib.vtts_hifigan_destroy(h)
     # unsupported configurations are rejected at create()
     bad = _lib.make_cfg(V1)

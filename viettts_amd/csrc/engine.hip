@@ -552,6 +552,17 @@ int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     return mb;
 }
 
+// The kernels index one utterance's activations with 32-bit row * channel products and the batch with blockIdx.z: a longer
+// utterance goes through the chunk scheduler (viettts_amd/longform.py: 13-frame halo), a larger batch in
+// several calls.
+int check_pass_size(const vtts_hifigan* h, int B, int T) {
+    if (max_act_elems(h, T) >= ((size_t)1 << 31))
+        return fail(VTTS_ERR_INVALID, "T=%d frames is too long for one pass (%zu activation elements per utterance, limit 2^31): synthesize it in chunks",
+                    T, max_act_elems(h, T));
+    if (pick_microbatch(h, B, T) > 65535) return fail(VTTS_ERR_INVALID, "at most 65535 utterances per pass (got %d)", B);
+    return VTTS_OK;
+}
+
 struct Taps {
     const char* name = nullptr;
     float* out = nullptr;
@@ -712,6 +723,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                  Taps tap) {
     if (!h->blob) return fail(VTTS_ERR_STATE, "forward() before pack()/bind_packed()");
     if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive (got B=%d, T=%d)", B, T);
+    if (int rc = check_pass_size(h, B, T)) return rc;
     size_t need = 0;
     vtts_hifigan_workspace_bytes(h, B, T, &need);
     if (ws_bytes < need || !ws) return fail(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
@@ -1033,6 +1045,7 @@ VTTS_API int vtts_hifigan_bind_packed(vtts_hifigan* h, void* dev_blob, size_t bl
 VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, size_t* bytes) {
     if (!h || !bytes) return fail(VTTS_ERR_INVALID, "null argument");
     if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive");
+    if (int rc = check_pass_size(h, B, T)) return rc;
     const int mb = pick_microbatch(h, B, T);
     const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
     *bytes = (size_t)num_streams(h, B, T) * 4 * align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
