@@ -105,9 +105,10 @@ int vtts_hifigan_packed_bytes(const vtts_hifigan* h, size_t* bytes);
 int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_bytes, vtts_stream stream);
 int vtts_hifigan_bind_packed(vtts_hifigan* h, void* dev_blob, size_t blob_bytes);
 
-/* Scratch bytes forward() needs for a batch of B utterances of T mel frames.  One pass takes utterances of fewer than
- * 2^31 / 8192 = 262144 frames (V1; 70 minutes at 16 kHz): longer ones return VTTS_ERR_INVALID here and in forward() and go
- * through the chunk scheduler (13-frame halo: the generator's receptive field). */
+/* Scratch bytes forward() needs for a batch of B utterances of T mel frames.  One pass takes utterances whose largest
+ * activation is below 2^31 bytes (V1: T < 131072 frames on the bf16 engine = 35 minutes at 16 kHz, T < 65536 on the fp32
+ * engine): longer ones return VTTS_ERR_INVALID here and in forward() and go through the chunk scheduler (13-frame halo: the
+ * generator's receptive field). */
 int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, size_t* bytes);
 
 /*

@@ -552,13 +552,14 @@ int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     return mb;
 }
 
-// The kernels index one utterance's activations with 32-bit row * channel products and the batch with blockIdx.z: a longer
-// utterance goes through the chunk scheduler (viettts_amd/longform.py: 13-frame halo), a larger batch in
+// The kernels may form one utterance's row * channel offsets (elements or bytes) in 32 bits and index the batch with
+// blockIdx.z: a longer utterance goes through the chunk scheduler (viettts_amd/longform.py: 13-frame halo), a larger batch in
 // several calls.
 int check_pass_size(const vtts_hifigan* h, int B, int T) {
-    if (max_act_elems(h, T) >= ((size_t)1 << 31))
-        return fail(VTTS_ERR_INVALID, "T=%d frames is too long for one pass (%zu activation elements per utterance, limit 2^31): synthesize it in chunks",
-                    T, max_act_elems(h, T));
+    const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
+    if (max_act_elems(h, T) * es >= ((size_t)1 << 31))
+        return fail(VTTS_ERR_INVALID, "T=%d frames is too long for one pass (%zu activation bytes per utterance, limit 2^31): synthesize it in chunks",
+                    T, max_act_elems(h, T) * es);
     if (pick_microbatch(h, B, T) > 65535) return fail(VTTS_ERR_INVALID, "at most 65535 utterances per pass (got %d)", B);
     return VTTS_OK;
 }
