@@ -322,4 +322,14 @@ def test_mel2wave_dropin(tmp_path, monkeypatch, v1_params, dev):
     assert wav2.shape == (2, 2560)
     with pytest.raises(ValueError):
         m2w.mel2wave(np.zeros((10, 80), np.float32))
+    # an utterance longer than one pass takes goes through the chunk scheduler (limit lowered for the test)
+    from viettts_amd.hifigan.generator import Generator
+
+    assert m2w._generator().max_frames_per_pass == 65536  # fp32 engine, V1: 2^31 bytes / (8192 * 4)
+    long_mel = synthetic_mel(1, 9000, 3)
+    one_shot = m2w.mel2wave(long_mel)
+    monkeypatch.setattr(Generator, "max_frames_per_pass", property(lambda self: 8192))
+    chunked = m2w.mel2wave(long_mel)
+    assert chunked.shape == one_shot.shape == (256 * 9000,)
+    assert np.abs(chunked - one_shot).max() < 5e-6
     m2w.reload()

@@ -64,6 +64,17 @@ class Generator:
 
     # ---- parameters -----------------------------------------------------------------------------
     @property
+    def max_frames_per_pass(self) -> int:
+        """Utterances of this many mel frames or more are refused by the C ABI (an utterance's largest activation must stay
+        below 2^31 bytes: include/vtts_hifigan.h, vtts_hifigan_workspace_bytes); they go through viettts_amd.longform."""
+        c, L, best = self.cfg.upsample_initial_channel, 1, self.cfg.upsample_initial_channel
+        for i, r in enumerate(self.cfg.upsample_rates):
+            L *= r
+            best = max(best, (c >> (i + 1)) * L)
+        es = 2 if self.dtype_name == "bf16" else 4
+        return -(-(1 << 31) // (best * es))
+
+    @property
     def packed_bytes(self) -> int:
         n = C.c_size_t(0)
         _lib.check(self.lib, self.lib.vtts_hifigan_packed_bytes(self._h, C.byref(n)))

@@ -79,6 +79,13 @@ def mel2wave(mel):
         m = torch.from_numpy(np.ascontiguousarray(np.asarray(mel), dtype=np.float32)).to(g.device)
     if m.dim() != 3:
         raise ValueError(f"mel must be [B, T, {g.cfg.num_mels}], got shape {tuple(m.shape)}")
-    wav = g(m)
+    if m.shape[1] >= g.max_frames_per_pass:
+        # longer than one pass of the kernels takes (the reference has no such limit: one shot, memory permitting): exact
+        # chunking with the receptive field as halo — the interior equals the one-shot result up to fp32 reassociation
+        from ..longform import synthesize_chunked
+
+        wav = torch.stack([synthesize_chunked(g, m[b].contiguous(), chunk_frames=4096, max_batch=8) for b in range(m.shape[0])])
+    else:
+        wav = g(m)
     # jnp.squeeze + jax.device_get (mel2wave.py:39-40); .cpu() synchronises the stream
     return np.squeeze(wav.cpu().numpy())
