@@ -4,11 +4,18 @@ CPU (numpy) restatement of the INFERENCE side of the reference's NAT networks
 (vietTTS/nat/model.py): ``DurationModel`` (:53-70) and ``AcousticModel.inference`` (:128-151), both built on
 ``TokenEncoder`` (:9-50), taking Haiku-layout parameter / state dicts.
 
-**Parity unpinned.**  The reference's tests for these modules (tests/test_nat_duration.py,
-tests/test_nat_acoustic.py) assert output SHAPES only, ship no vector, and need jax + dm-haiku, which cannot be
-installed here; no NAT checkpoint ships with the reference either.  Unlike the HiFi-GAN
-oracle there is no second implementation inside the reference to pin against.  What is restated below is the
-published behaviour of the third-party modules the reference calls (dm-haiku / jax, unpinned in setup.py:6-19):
+**Parity: the WIRING is pinned to the reference's own code, executed; the third-party primitives are not.**
+* Pinned (round 2): ``oracle/make_nat_golden.py`` imports the reference's ``vietTTS/nat/text2mel.py`` and ``vietTTS/nat/model.py``
+  from /root/reference and runs ``text2mel`` / ``predict_duration`` / ``predict_mel`` UNCHANGED on seeded synthetic checkpoints,
+  with ``oracle/haiku_shim.py`` standing in for haiku / jax; the fixture ``tests/golden/nat_text2mel_golden.npz`` holds what they
+  return.  ``duration_model`` below reproduces it bit for bit and ``acoustic_inference`` (with ``haiku_prenet_keep_masks``) to
+  3e-15 (tests/test_nat_cpu.py): layer order, masks, the skip-connection order, the order of rng draws behind the always-on
+  prenet dropout, text2mel's silence rules and frame arithmetic are the reference's.
+* **Unpinned by a JAX run**: the primitives themselves.  The reference's tests for these modules (tests/test_nat_duration.py,
+  tests/test_nat_acoustic.py) assert output SHAPES only, ship no vector, and need jax + dm-haiku, which cannot be installed here
+  (SURVEY.md §4, Appendix D); no NAT checkpoint ships with the reference either.  The shim's primitives ARE the functions below, so
+  a wrong reading of one of them is shared and not caught.  What is restated is the published behaviour of the third-party modules
+  the reference calls (dm-haiku / jax, unpinned in setup.py:6-19):
 
 * ``hk.Embed``        gather rows of ``embeddings[V, D]``
 * ``hk.Conv1D(C, k)`` default ``padding="SAME"``, stride 1: cross-correlation, ``w[k, Cin, Cout]``, pads ((k-1)//2, k//2)

@@ -169,6 +169,41 @@ def test_text2mel_to_waveform_pipeline(model, acoustic, tmp_path):
         t2m.set_acoustic_model(None)
 
 
+def test_text2mel_equals_the_reference_code_executed(tmp_path, monkeypatch):
+    """The product's text2mel — checkpoints read from ``assets/infore/nat/*.pickle`` under the CWD as the reference does, both
+    networks on the GPU, the checkpoint's rng behind the prenet dropout — against the mel the REFERENCE'S OWN text2mel.py /
+    model.py produced for the same text, lexicon, silence_duration and checkpoints (tests/golden/nat_text2mel_golden.npz,
+    minted by oracle/make_nat_golden.py under oracle/haiku_shim.py; float64): the frame counts are equal, the mel within fp32
+    accumulation error of an autoregressive loop a few hundred frames long."""
+    from pathlib import Path
+
+    from oracle.make_nat_golden import write_checkpoints
+
+    g = np.load(Path(__file__).parent / "golden" / "nat_text2mel_golden.npz")
+    assert write_checkpoints(tmp_path) == str(g["params_sha256"])
+    lexicon = Path(__file__).parent / "golden" / "text" / "lexicon.txt"
+    monkeypatch.chdir(tmp_path)
+    t2m.set_duration_model(None)
+    t2m.set_acoustic_model(None)
+    try:
+        for ci in range(int(g["n_cases"])):
+            p = f"c{ci}_"
+            text, sil = str(g[p + "text"]), float(g[p + "silence_duration"])
+            tokens = t2m.text2tokens(text, lexicon)
+            assert tokens == [int(t) for t in g[p + "tokens"]]
+            dur = t2m.predict_duration(tokens)
+            assert np.abs(dur.astype(np.float64) - g[p + "durations_s"]).max() < 5e-6
+            mel = t2m.text2mel(text, lexicon, sil)
+            want = g[p + "mel_full"][: int(g[p + "n_frames"]) - int(g[p + "trailing_frames"])]
+            assert mel.shape == (1,) + want.shape, (mel.shape, want.shape)  # integer frame counts: bit-exact
+            err = float(np.abs(mel[0].astype(np.float64) - want).max())
+            print(f"[text2mel vs the reference's code, case {ci}: {want.shape[0]} frames] max|d mel| {err:.2e} (|mel| max {np.abs(want).max():.2f})")
+            assert err < 5e-5  # observed 3e-6
+    finally:
+        t2m.set_duration_model(None)
+        t2m.set_acoustic_model(None)
+
+
 def test_pipeline_sharded_equals_unsharded(model, acoustic):
     """configs[3] on one GPU: 24 sentences through the batched pipeline; the union of two ranks' shards equals the
     single-rank result bit for bit (rows are independent at every stage; no exchange step)."""

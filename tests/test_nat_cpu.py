@@ -9,6 +9,8 @@ import pytest
 
 from oracle import nat_oracle as no
 from viettts_amd import _lib
+from viettts_amd.nat import text2mel as t2m
+from viettts_amd.nat.config import FLAGS
 from viettts_amd.nat.synth import synthetic_duration_checkpoint
 
 REPO = Path(__file__).resolve().parents[1]
@@ -180,3 +182,57 @@ def test_jax_legacy_prng_known_answers_and_haiku_mask_schedule():
         key, sub = jax_legacy_split(key, 2)
     assert np.array_equal(m[1, 0], jax_legacy_uniform(sub, 256) < np.float32(0.5))
     assert not np.array_equal(m[0, 0], m[0, 1])
+
+
+# ---- the reference's own NAT code, executed (oracle/make_nat_golden.py: vietTTS/nat/text2mel.py + model.py from /root/reference under
+# ---- oracle/haiku_shim.py) -------------------------------------------------------------------------------------------------------
+NAT_GOLDEN = Path(__file__).parent / "golden" / "nat_text2mel_golden.npz"
+
+
+def _synthetic_checkpoints_checked(g):
+    from oracle.make_nat_golden import params_digest
+    from viettts_amd.nat.synth import synthetic_acoustic_checkpoint
+
+    dp, ds = synthetic_duration_checkpoint()
+    ap, as_ = synthetic_acoustic_checkpoint()
+    assert params_digest(dp, ds, ap, as_) == str(g["params_sha256"]), "the seeded synthetic checkpoints differ from the ones the fixture was minted with"
+    return dp, ds, ap, as_
+
+
+def test_oracle_equals_the_reference_code_executed():
+    """oracle/nat_oracle.py (the restatement every GPU test is checked against) against the output of the reference's own
+    text2mel.py / model.py: durations bit for bit, mel to fp64 rounding — the wiring, the skip-connection order, the order of rng
+    draws behind the always-on prenet dropout and the frame arithmetic are the reference's."""
+    g = np.load(NAT_GOLDEN)
+    dp, ds, ap, as_ = _synthetic_checkpoints_checked(g)
+    for ci in range(2):
+        p = f"c{ci}_"
+        tok = g[p + "tokens"]
+        assert [int(t) for t in tok] == t2m.text2tokens(str(g[p + "text"]), Path(__file__).parent / "golden" / "text" / "lexicon.txt")
+        d = no.duration_model(dp, ds, tok, dtype=np.float64)
+        assert np.abs(d - g[p + "durations_s"][0]).max() < 1e-13
+        ruled = t2m.apply_duration_rules([int(t) for t in tok], g[p + "durations_s"], float(g[p + "silence_duration"]))
+        assert np.abs(np.asarray(ruled, np.float64) - g[p + "durations_ruled_s"]).max() < 1e-7  # the product's rules run in float32
+        nf = int(g[p + "n_frames"])
+        assert t2m.n_frames_from_durations(ruled) == nf and t2m.trailing_silence_frames(ruled) == int(g[p + "trailing_frames"])
+        masks = no.haiku_prenet_keep_masks(g["rng_key"], nf)
+        frames = g[p + "durations_ruled_s"][0] * FLAGS.sample_rate / (FLAGS.n_fft // 4)
+        mel = no.acoustic_inference(ap, as_, tok, frames, nf, prenet_masks=lambda t: (masks[t, 0], masks[t, 1]), dtype=np.float64)
+        assert np.abs(mel - g[p + "mel_full"]).max() < 1e-11
+
+
+@pytest.mark.skipif(not Path("/root/reference/vietTTS/nat/model.py").exists(), reason="needs /root/reference (build container only)")
+def test_reference_nat_code_reproduces_the_committed_fixture(tmp_path):
+    """Re-mint the fixture from the reference's files and compare with the committed one (where the reference exists)."""
+    import os
+    import subprocess
+    import sys
+
+    out = tmp_path / "again.npz"
+    env = dict(os.environ, VTTS_NAT_GOLDEN_OUT=str(out))
+    r = subprocess.run([sys.executable, str(Path(__file__).parents[1] / "oracle" / "make_nat_golden.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b = np.load(NAT_GOLDEN), np.load(out)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
