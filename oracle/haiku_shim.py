@@ -29,6 +29,7 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
+from . import hifigan_oracle as H
 from . import nat_oracle as O
 
 _DTYPE = [np.float64]
@@ -77,20 +78,11 @@ class _ModuleMeta(type):
     def __call__(cls, *args, **kwargs):
         fr = _frame()
         obj = cls.__new__(cls)
-        base = kwargs.get("name") or _snake(cls.__name__)
-        if fr.stack:
-            parent, method, cnt = fr.stack[-1]
-            prefix = parent.module_name + ("/~/" if method == "__init__" else "/")
-        else:
-            prefix, cnt = "", fr.top_counters
-        # Haiku numbers siblings per method INVOCATION (a fresh counter is pushed on every wrapped call): the hk.Linear that
-        # hk.LSTM.__call__ builds is "linear" at every step, the three hk.Conv1D of one __init__ are conv1_d, conv1_d_1, conv1_d_2
-        n = cnt.get(base, 0)
-        cnt[base] = n + 1
-        obj.module_name = prefix + (base if n == 0 else f"{base}_{n}")
         fr.stack.append((obj, "__init__", {}))
         try:
-            obj.__init__(*args, **kwargs)
+            obj.__init__(*args, **kwargs)  # Module.__init__ (reached through super().__init__(name=...)) names the instance
+            if not hasattr(obj, "module_name"):
+                raise RuntimeError(f"{cls.__name__}.__init__ never called super().__init__() (Haiku raises here too)")
         finally:
             fr.stack.pop()
         return obj
@@ -111,7 +103,21 @@ def _scoped(method_name, fn):
 
 class Module(metaclass=_ModuleMeta):
     def __init__(self, name: Optional[str] = None):
-        pass
+        """Haiku names the module HERE, from the scope that is creating it: ``<parent>/~/<name>`` inside the parent's ``__init__``,
+        ``<parent>/<name>`` inside another of its methods; siblings of one method INVOCATION are numbered (a fresh counter per
+        wrapped call: the hk.Linear that hk.LSTM.__call__ builds is "linear" at every step; the three hk.Conv1D of one __init__ are
+        conv1_d, conv1_d_1, conv1_d_2)."""
+        fr = _frame()
+        assert fr.stack and fr.stack[-1][0] is self, "Module.__init__ outside its constructor"
+        base = name or _snake(type(self).__name__)
+        if len(fr.stack) >= 2:
+            parent, method, cnt = fr.stack[-2]
+            prefix = parent.module_name + ("/~/" if method == "__init__" else "/")
+        else:
+            prefix, cnt = "", fr.top_counters
+        n = cnt.get(base, 0)
+        cnt[base] = n + 1
+        self.module_name = prefix + (base if n == 0 else f"{base}_{n}")
 
 
 def _current_module() -> Module:
@@ -161,7 +167,7 @@ def dropout(rng, rate: float, x):
 # ---------------------------------------------------------------------------------------------------------------------
 class Embed(Module):
     def __init__(self, vocab_size, embed_dim, name=None):
-        pass
+        super().__init__(name=name)
 
     def __call__(self, ids):
         return get_parameter("embeddings")[np.asarray(ids)]
@@ -169,6 +175,7 @@ class Embed(Module):
 
 class Linear(Module):
     def __init__(self, output_size, with_bias=True, name=None):
+        super().__init__(name=name)
         self.with_bias = with_bias
 
     def __call__(self, x):
@@ -177,12 +184,33 @@ class Linear(Module):
 
 
 class Conv1D(Module):
-    def __init__(self, output_channels, kernel_shape, padding="SAME", name=None):
-        assert padding == "SAME"
+    """hk.Conv1D(output_channels, kernel_shape, stride=1, rate=1, padding="SAME" | ((lo, hi),)): NWC, w [k, Cin, Cout], cross-correlation."""
+
+    def __init__(self, output_channels, kernel_shape, stride=1, rate=1, padding="SAME", name=None):
+        super().__init__(name=name)
+        assert stride == 1
+        self.rate, self.padding = rate, padding
 
     def __call__(self, x):  # [B, L, C]
         w, b = get_parameter("w"), get_parameter("b")
-        return np.stack([O.conv1d_same(np.asarray(xb), w, b) for xb in x])
+        if self.padding == "SAME":
+            assert self.rate == 1
+            return np.stack([O.conv1d_same(np.asarray(xb), w, b) for xb in x])
+        (lo, hi), = self.padding
+        assert lo == hi
+        return H.conv1d(np.asarray(x), w, b, self.rate, lo)
+
+
+class Conv1DTranspose(Module):
+    """hk.Conv1DTranspose(output_channels, kernel_shape, stride, padding="SAME"): w [k, Cout, Cin] (oracle/hifigan_oracle.py)."""
+
+    def __init__(self, output_channels, kernel_shape=None, stride=1, padding="SAME", name=None):
+        super().__init__(name=name)
+        assert padding == "SAME"
+        self.stride = stride
+
+    def __call__(self, x):
+        return H.conv1d_transpose(np.asarray(x), get_parameter("w"), get_parameter("b"), self.stride)
 
 
 class _Ema(Module):
@@ -191,6 +219,7 @@ class _Ema(Module):
 
 class BatchNorm(Module):
     def __init__(self, create_scale, create_offset, decay_rate, name=None):
+        super().__init__(name=name)
         self.mean_ema = _Ema(name="mean_ema")
         self.var_ema = _Ema(name="var_ema")
 
@@ -209,6 +238,7 @@ class RNNCore(Module):
 
 class LSTM(RNNCore):
     def __init__(self, hidden_size, name=None):
+        super().__init__(name=name)
         self.hidden_size = hidden_size
 
     def initial_state(self, batch_size):
@@ -231,6 +261,7 @@ class ResetCore(RNNCore):
     """hk.ResetCore: ``state = where(should_reset, initial_state, state)`` BEFORE the wrapped core's step."""
 
     def __init__(self, core, name=None):
+        super().__init__(name=name)
         self.core = core
 
     def initial_state(self, batch_size):
@@ -249,6 +280,7 @@ class _DeepRNN(RNNCore):
     the output is the concatenation of every layer's output."""
 
     def __init__(self, layers, name=None):
+        super().__init__(name=name)
         self.layers = list(layers)
 
     def initial_state(self, batch_size):
@@ -271,6 +303,7 @@ def deep_rnn_with_skip_connections(layers, name=None):
 
 class Sequential(Module):
     def __init__(self, layers, name=None):
+        super().__init__(name=name)
         self.layers = list(layers)
 
     def __call__(self, x):
@@ -311,6 +344,22 @@ class _Transformed:
 
 def transform_with_state(fn):
     return _Transformed(fn)
+
+
+class PRNGSequence:
+    """hk.PRNGSequence(seed or key): ``next`` = reserve(1) = split(key, 2), hand out the second."""
+
+    def __init__(self, key_or_seed):
+        self.key = (np.array([0, int(key_or_seed) & 0xFFFFFFFF], np.uint32) if np.isscalar(key_or_seed)
+                    else np.asarray(key_or_seed, np.uint32).reshape(2))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        ks = O.jax_legacy_split(self.key, 2)
+        self.key = ks[0]
+        return ks[1]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -359,7 +408,7 @@ def _device_get(x):
 def _build_modules() -> Dict[str, types.ModuleType]:
     hk = types.ModuleType("haiku")
     for k, v in dict(Module=Module, Embed=Embed, Linear=Linear, Conv1D=Conv1D, BatchNorm=BatchNorm, LSTM=LSTM, LSTMState=LSTMState, RNNCore=RNNCore,
-                     ResetCore=ResetCore, Sequential=Sequential, dropout=dropout, next_rng_key=next_rng_key, set_state=set_state,
+                     ResetCore=ResetCore, Sequential=Sequential, Conv1DTranspose=Conv1DTranspose, PRNGSequence=PRNGSequence, dropout=dropout, next_rng_key=next_rng_key, set_state=set_state,
                      dynamic_unroll=dynamic_unroll, deep_rnn_with_skip_connections=deep_rnn_with_skip_connections,
                      transform_with_state=transform_with_state).items():
         setattr(hk, k, v)
@@ -375,6 +424,7 @@ def _build_modules() -> Dict[str, types.ModuleType]:
     nn.gelu = lambda x, approximate=True: O.gelu_tanh(np.asarray(x))
     nn.softplus = lambda x: O.softplus(np.asarray(x))
     nn.softmax = _softmax
+    nn.leaky_relu = lambda x, negative_slope=0.01: H.leaky_relu(np.asarray(x), negative_slope)
 
     rnd = types.ModuleType("jax.random")
     rnd.split = lambda key, num=2: O.jax_legacy_split(np.asarray(key, np.uint32), num)

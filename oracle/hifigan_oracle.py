@@ -11,7 +11,11 @@ dm-haiku absent).  The oracle is therefore pinned against outputs of the referen
 PyTorch generator (vietTTS/hifigan/torch_model.py:156-218 — the model the Haiku weights
 are converted from) run in the build container by oracle/make_golden.py, through the
 reference's own converter (vietTTS/hifigan/convert_torch_model_to_haiku.py:27-62); those
-outputs are committed under tests/golden/.  Third-party arithmetic restated here:
+outputs are committed under tests/golden/.  Since round 2 the same fixtures also hold ``y64_haiku``: the output of the
+reference's HAIKU generator itself — vietTTS/hifigan/model.py + mel2wave.py imported from /root/reference and executed
+unchanged over oracle/haiku_shim.py (whose convolutions are the two primitives below) — which equals the torch generator's to
+2e-15: the wiring and module names of the module the product replaces are the reference's, executed; the primitives are pinned
+numerically by the torch twin through the converter's layout map.  Third-party arithmetic restated here:
 dm-haiku ``hk.Conv1D`` / ``hk.Conv1DTranspose`` and jax ``lax.conv_general_dilated`` /
 ``lax.conv_transpose`` / ``jax.nn.leaky_relu`` / ``jnp.tanh`` (unpinned in the reference's
 setup.py:6-19).

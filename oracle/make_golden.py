@@ -134,6 +134,35 @@ def check_converter(tm, conv, cfg, params, workdir: Path):
     return worst, exact, worst2, ref_hk
 
 
+def reference_haiku_mel2wave(cfg, params, mel):
+    """The reference's HAIKU generator, executed: ``vietTTS/hifigan/mel2wave.py::mel2wave`` (with ``model.py``'s Generator /
+    ResBlock1 / ResBlock2) imported from /root/reference and run unchanged — config from ``assets/hifigan/config.json`` and
+    weights from ``./assets/infore/hifigan/hk_hifi.pickle`` under a scratch CWD, as it reads them — over oracle/haiku_shim.py
+    (jax / haiku cannot be installed here), in float64.  The shim's convolutions are oracle/hifigan_oracle.py's; what this run
+    adds is the Haiku model's own wiring and module names (the pickle keys are whatever model.py's modules ask for)."""
+    from oracle import haiku_shim as shim
+
+    shim.install()
+    shim.set_dtype(np.float64)
+    import vietTTS.hifigan.mel2wave as ref_m2w  # noqa: E402  (the reference's file, unchanged; `vietTTS` is already the reference's package)
+
+    assert Path(ref_m2w.__file__).resolve().is_relative_to(REF), ref_m2w.__file__
+    with tempfile.TemporaryDirectory() as td:
+        td = Path(td)
+        (td / "assets/hifigan").mkdir(parents=True)
+        (td / "assets/infore/hifigan").mkdir(parents=True)
+        with open(td / "assets/hifigan/config.json", "w") as f:
+            json.dump(dict(cfg_to_h(cfg)), f)
+        with open(td / "assets/infore/hifigan/hk_hifi.pickle", "wb") as f:
+            pickle.dump({k: {n: np.asarray(a) for n, a in m.items()} for k, m in params.items()}, f)
+        cwd = os.getcwd()
+        os.chdir(td)
+        try:
+            return np.asarray(ref_m2w.mel2wave(np.asarray(mel, dtype=np.float64)))
+        finally:
+            os.chdir(cwd)
+
+
 def mint_converter_golden(tm, conv, out: Path):
     """A weight-norm checkpoint of the TINY architecture (g != ||v||, so the fold matters) and what the REFERENCE converter
     (convert_torch_model_to_haiku.py:27-62) writes for it: tests/golden/convert_tiny.npz — pins the converter entry point
@@ -237,6 +266,13 @@ def main():
             arrs["mel"] = mel
         if full:
             arrs.update(y32=y32.astype(np.float32), y64=y64.astype(np.float64), pre32=p32.astype(np.float32), pre64=p64.astype(np.float64))
+            # the reference's OTHER implementation of the same generator — the Haiku one the product replaces — executed over the shim
+            yhk = reference_haiku_mel2wave(cfg, params, mel)
+            d = float(np.abs(yhk - np.squeeze(y64)).max())
+            print(f"[{name}] reference Haiku mel2wave (model.py + mel2wave.py over oracle/haiku_shim.py) vs reference torch generator, fp64: max|dy| = {d:.3e}")
+            assert yhk.shape == np.squeeze(y64).shape and d < 1e-12
+            arrs["y64_haiku"] = yhk.astype(np.float64)
+            rec["haiku_vs_torch_maxabs"] = d
         else:
             idx = np.arange(0, y64.shape[1], 61)
             arrs.update(idx=idx, y32=y32[:, idx].astype(np.float32), y64=y64[:, idx], pre32=p32[:, idx].astype(np.float32), pre64=p64[:, idx],

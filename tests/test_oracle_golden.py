@@ -41,6 +41,10 @@ def test_oracle_matches_reference_full(golden_dir, case):
     # fp64 restatement of the Haiku semantics == fp64 reference torch generator
     assert np.abs(y[..., 0] - g["y64"]).max() < 1e-12
     assert np.abs(pre[..., 0] - g["pre64"]).max() < 1e-12
+    # ... == the reference's HAIKU generator (vietTTS/hifigan/model.py + mel2wave.py from /root/reference, executed over
+    # oracle/haiku_shim.py by oracle/make_golden.py::reference_haiku_mel2wave): the module the product replaces, its own wiring and names
+    assert np.abs(np.squeeze(y[..., 0]) - g["y64_haiku"]).max() < 1e-12
+    assert np.abs(np.squeeze(g["y64"]) - g["y64_haiku"]).max() < 1e-12 and rec["haiku_vs_torch_maxabs"] < 1e-12
     # and the reference's fp32 run sits at fp32 round-off from it
     assert np.abs(y[..., 0] - g["y32"]).max() < 2e-5
     # fp32 mode of the oracle (what the cpu_baseline leg times) is equally close
@@ -146,3 +150,30 @@ def test_built_reference_archive_matches_golden(golden_dir):
         y = ts(torch.from_numpy(mel).permute(0, 2, 1).contiguous())[:, 0].numpy()
     assert np.abs(y - g["y32"]).max() < 1e-6  # same graph, same weights (thread-count reassociation only)
     assert np.abs(y - g["y64"]).max() < 2e-5
+
+
+@pytest.mark.skipif(not __import__("pathlib").Path("/root/reference/vietTTS/hifigan/model.py").exists(), reason="needs /root/reference (build container only)")
+def test_reference_haiku_generator_reproduces_the_committed_fixture(golden_dir):
+    """Run the reference's Haiku mel2wave again (over the shim, in a subprocess: it installs stand-in `jax` / `haiku` modules) and
+    compare with the committed `y64_haiku` of the TINY fixture, whose weights and mel are in the file."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from oracle import make_golden as mg
+        mg._import_reference()
+        g = np.load(%r)
+        params = {}
+        for name in g.files:
+            if name.startswith("W::"):
+                _, key, which = name.split("::")
+                params.setdefault(key, {})[which] = g[name]
+        y = mg.reference_haiku_mel2wave(mg.TINY, params, g["mel"])
+        assert np.array_equal(y, g["y64_haiku"]), float(np.abs(y - g["y64_haiku"]).max())
+        print("same")
+    """) % (str(golden_dir.parents[1]), str(golden_dir / "tiny_scaled_T12.npz"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "same" in r.stdout, r.stdout + r.stderr
