@@ -151,3 +151,36 @@ def test_frame_plan_equals_the_per_sentence_rules_bit_for_bit():
             assert np.array_equal(frames[i], t2m.durations_to_frames(d)[0]) and frames[i].dtype == np.float32
             assert nfr[i] == t2m.n_frames_from_durations(d)
             assert trail[i] == (t2m.trailing_silence_frames(d) if t[-1] == FLAGS.sil_index else 0)
+
+
+def test_normalised_text_equals_the_reference_cli_print():
+    """The line the reference's CLI printed when it was executed (tests/golden/synthesizer_golden.npz, oracle/make_synth_golden.py)."""
+    import json
+
+    import numpy as np
+
+    from viettts_amd.synthesizer import nat_normalize_text
+
+    g = np.load(Path(__file__).parent / "golden" / "synthesizer_golden.npz")
+    lines = json.loads(str(g["stdout"]))
+    assert lines[0] == "Normalized text input: " + nat_normalize_text(str(g["text"]))
+    assert lines[1] == "writing output to file out.wav"
+
+
+@pytest.mark.skipif(not Path("/root/reference/vietTTS/synthesizer.py").exists(), reason="needs /root/reference (build container only)")
+def test_reference_cli_reproduces_the_committed_fixture(tmp_path):
+    """Run the reference's CLI again (oracle/make_synth_golden.py, over the haiku / jax stand-in) and compare with the committed fixture."""
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    out = tmp_path / "again.npz"
+    r = subprocess.run([sys.executable, str(Path(__file__).parents[1] / "oracle" / "make_synth_golden.py")], env=dict(os.environ, VTTS_SYNTH_GOLDEN_OUT=str(out)),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b = np.load(Path(__file__).parent / "golden" / "synthesizer_golden.npz"), np.load(out)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k

@@ -80,3 +80,30 @@ def test_cli_mel_file(tmp_path):
     want = float_to_pcm16(mel2wave_oracle(params, mel, V1))
     assert sr == 16000 and len(pcm) == 12 * 256
     assert np.abs(pcm.astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
+def test_cli_text_to_wav_equals_the_reference_cli_executed(tmp_path):
+    """``python -m vietTTS.synthesizer --text ... --output ... --lexicon-file ... --silence-duration ...`` of THIS repo (text ->
+    tokens -> durations and mel on the GPU -> HiFi-GAN on the GPU -> PCM16 WAV) against what the REFERENCE'S CLI produced for the
+    same arguments and the same files under its CWD (tests/golden/synthesizer_golden.npz: vietTTS/synthesizer.py and everything it
+    imports, run from /root/reference by oracle/make_synth_golden.py over oracle/haiku_shim.py; float64): same two printed lines,
+    same number of samples, every PCM16 sample within 1 LSB."""
+    import json
+
+    from oracle.make_synth_golden import write_assets
+    from viettts_amd.wavio import float_to_pcm16, read_wav
+
+    g = np.load(os.path.join(REPO, "tests", "golden", "synthesizer_golden.npz"))
+    assert write_assets(tmp_path) == str(g["nat_params_sha256"])
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, "-m", "vietTTS.synthesizer", "--text", str(g["text"]), "--output", "out.wav", "--lexicon-file",
+                        os.path.join(REPO, str(g["lexicon"])), "--silence-duration", str(float(g["silence_duration"]))],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert [l for l in r.stdout.splitlines() if l.strip()] == json.loads(str(g["stdout"]))
+    sr, pcm = read_wav(tmp_path / "out.wav")
+    want = float_to_pcm16(g["wave"])
+    assert sr == int(g["samplerate"]) and pcm.shape == want.shape  # the integer frame count of the whole chain: bit-exact
+    d = np.abs(pcm.astype(np.int32) - want.astype(np.int32))
+    print(f"[CLI vs the reference's CLI: {pcm.shape[0]} samples] max |d PCM16| {int(d.max())} LSB, {float((d > 0).mean()) * 100:.2f} % of samples differ; |pcm| max {int(np.abs(want).max())}")
+    assert d.max() <= 1
