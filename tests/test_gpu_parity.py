@@ -161,6 +161,10 @@ def test_generator_matches_reference_golden(golden_dir, dev, case, kernels):
     e_ref32 = np.abs(wav - g["y32"]).max()
     assert e_y < TIGHT and e_p < TIGHT and e_ref32 < TIGHT, (e_y, e_p, e_ref32)
     assert e_y < TOL
+    # north_star's own sentence — "outputs match the HAIKU generator on identical mel inputs within 1e-4 max-abs fp32" — against the
+    # reference's Haiku mel2wave executed (oracle/make_golden.py::reference_haiku_mel2wave): squeezed as mel2wave.py:39 returns it
+    e_hk = np.abs(np.squeeze(wav) - g["y64_haiku"]).max()
+    assert e_hk < TIGHT and e_hk < 1e-4, e_hk
 
 
 def test_tiny_architecture_rng_independent(golden_dir, dev):
