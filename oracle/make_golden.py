@@ -275,6 +275,13 @@ def main():
             rec["haiku_vs_torch_maxabs"] = d
         else:
             idx = np.arange(0, y64.shape[1], 61)
+            if name == "v1_scaled_T512":  # BASELINE configs[1]'s own shape: the Haiku generator executed there too (B = 1)
+                yhk = reference_haiku_mel2wave(cfg, params, mel)
+                d = float(np.abs(yhk - np.squeeze(y64)).max())
+                print(f"[{name}] reference Haiku mel2wave vs reference torch generator, fp64: max|dy| = {d:.3e}")
+                assert yhk.shape == np.squeeze(y64).shape and d < 1e-12
+                arrs["y64_haiku"] = yhk[idx].astype(np.float64)
+                rec["haiku_vs_torch_maxabs"] = d
             arrs.update(idx=idx, y32=y32[:, idx].astype(np.float32), y64=y64[:, idx], pre32=p32[:, idx].astype(np.float32), pre64=p64[:, idx],
                         sum_y64=np.array([y64.sum(), np.abs(y64).sum(), (y64 ** 2).sum()]),
                         sum_pre64=np.array([p64.sum(), np.abs(p64).sum(), (p64 ** 2).sum()]))

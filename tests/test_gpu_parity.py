@@ -226,6 +226,10 @@ def test_baseline_config2_shape(golden_dir, gen_v1, dev):
     idx = g["idx"]
     e_y, e_p = np.abs(wav[:, idx] - g["y64"]).max(), np.abs(pre[:, idx] - g["pre64"]).max()
     assert e_y < TIGHT and e_p < TIGHT, (e_y, e_p)
+    # ... and vs the reference's HAIKU mel2wave executed at this shape (BASELINE configs[1]: "parity vs Haiku ref <= 1e-4")
+    e_hk = np.abs(wav[0, idx] - g["y64_haiku"]).max()
+    print(f"[fp32 B=1 T=512 vs the reference's Haiku mel2wave executed] max|dy| {e_hk:.3e}")
+    assert e_hk < TIGHT and e_hk < 1e-4
     s = g["sum_y64"]
     w64 = wav.astype(np.float64)
     assert abs(np.abs(w64).sum() - s[1]) / s[1] < 1e-5

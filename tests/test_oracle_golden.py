@@ -83,6 +83,7 @@ def test_oracle_matches_reference_baseline_shape(golden_dir):
     idx = g["idx"]
     assert np.abs(y[:, idx, 0] - g["y64"]).max() < 2e-5
     assert np.abs(pre[:, idx, 0] - g["pre64"]).max() < 2e-5
+    assert np.abs(g["y64"][0] - g["y64_haiku"]).max() < 1e-12  # the reference's Haiku generator executed == its torch generator, here too
     s = g["sum_y64"]
     y64 = y[..., 0].astype(np.float64)
     assert abs(np.abs(y64).sum() - s[1]) / s[1] < 1e-5
