@@ -236,3 +236,84 @@ def test_reference_nat_code_reproduces_the_committed_fixture(tmp_path):
     assert sorted(a.files) == sorted(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_checkpoint_with_haiku_and_jax_objects_loads_without_those_libraries(tmp_path):
+    """A checkpoint pickled the way the reference pickles it (vietTTS/nat/utils.py:18-26: Haiku mappings of jax arrays, an optax state)
+    read where none of those libraries exists.  The classes are EMULATED here under their real module paths (pickling hooks restated
+    from the libraries: FlatMapping reduces to its plain mapping, a jax array to numpy's reduce tuple + an aval state) and removed from
+    ``sys.modules`` before loading; no real checkpoint is available offline to confirm the formats (viettts_amd/nat/ckpt.py)."""
+    import pickle
+    import sys
+    import types
+    from collections import namedtuple
+
+    from viettts_amd.nat.ckpt import CheckpointFormatError, load_checkpoint
+
+    fake = {}
+
+    def mod(name):
+        m = types.ModuleType(name)
+        fake[name] = m
+        sys.modules[name] = m
+        return m
+
+    for n in ("haiku", "haiku._src", "jax", "jax._src", "optax", "optax._src"):
+        mod(n)
+    ds, arr, tr = mod("haiku._src.data_structures"), mod("jax._src.array"), mod("optax._src.transform")
+
+    class FlatMapping(dict):
+        def __reduce__(self):
+            return (FlatMapping, (dict(self),))
+
+    FlatMapping.__module__, FlatMapping.__qualname__ = ds.__name__, "FlatMapping"
+    ds.FlatMapping = FlatMapping
+
+    def _reconstruct_array(fun, args, arr_state, aval_state):
+        raise AssertionError("the real constructor must not be needed")
+
+    _reconstruct_array.__module__, _reconstruct_array.__qualname__ = arr.__name__, "_reconstruct_array"
+    arr._reconstruct_array = _reconstruct_array
+
+    class ArrayImpl:
+        def __init__(self, v):
+            self.v = np.asarray(v)
+
+        def __reduce__(self):
+            fun, args, state = self.v.__reduce__()
+            return (_reconstruct_array, (fun, args, state, {"weak_type": False, "named_shape": {}}))
+
+    ArrayImpl.__module__, ArrayImpl.__qualname__ = arr.__name__, "ArrayImpl"
+    arr.ArrayImpl = ArrayImpl
+    ScaleByAdamState = namedtuple("ScaleByAdamState", ["count", "mu", "nu"])
+    ScaleByAdamState.__module__, ScaleByAdamState.__qualname__ = tr.__name__, "ScaleByAdamState"
+    tr.ScaleByAdamState = ScaleByAdamState
+
+    P, S = synthetic_duration_checkpoint()
+    wrap = lambda d: FlatMapping({k: FlatMapping({n: ArrayImpl(a) for n, a in v.items()}) for k, v in d.items()})
+    dic = {"step": 7, "params": wrap(P), "aux": wrap(S), "rng": ArrayImpl(np.array([1, 2], np.uint32)),
+           "optim_state": (ScaleByAdamState(ArrayImpl(np.zeros((), np.int32)), wrap(P), wrap(P)),)}
+    path = tmp_path / "duration_latest_ckpt.pickle"
+    try:
+        with open(path, "wb") as f:
+            pickle.dump(dic, f)
+    finally:
+        for n in fake:
+            del sys.modules[n]
+    with pytest.raises(ModuleNotFoundError):
+        with open(path, "rb") as f:
+            pickle.load(f)  # what the reference's loader does: needs haiku / jax / optax
+    got = load_checkpoint(path)
+    assert got["step"] == 7 and sorted(got["params"]) == sorted(P) and sorted(got["aux"]) == sorted(S)
+    for k in P:
+        for n in P[k]:
+            assert isinstance(got["params"][k][n], np.ndarray) and np.array_equal(got["params"][k][n], P[k][n])
+    assert np.array_equal(got["rng"], np.array([1, 2], np.uint32))
+    params, state = t2m.load_duration_checkpoint(path)
+    assert np.array_equal(params["duration_model/~/linear_1"]["b"], P["duration_model/~/linear_1"]["b"]) and sorted(state) == sorted(S)
+    # a layout it cannot recognise is refused by name, not guessed
+    from viettts_amd.nat import ckpt as ck
+
+    weird = ck._absent_class("haiku._src.data_structures", "Mystery")({"a": 1}, {"b": 2})
+    with pytest.raises(CheckpointFormatError, match="Mystery"):
+        ck.to_plain(weird)

@@ -140,15 +140,13 @@ _DURATION_MODEL = None
 
 def load_duration_checkpoint(path=None):
     """``dic["params"], dic["aux"]`` of ``duration_latest_ckpt.pickle`` (text2mel.py:27-28, written by
-    vietTTS/nat/utils.py:18-24).  Checkpoints whose dicts were pickled as plain numpy dicts load as they are; ones
-    holding Haiku FlatMapping / jax arrays need those libraries to unpickle, as in the reference."""
-    import pickle
+    vietTTS/nat/utils.py:18-24) as ``{module: {name: ndarray}}``.  Checkpoints pickled as plain numpy dicts load as they are; ones
+    holding Haiku mappings / jax arrays are read without those libraries, best effort (viettts_amd/nat/ckpt.py)."""
+    from .ckpt import load_checkpoint
 
     path = FLAGS.ckpt_dir / "duration_latest_ckpt.pickle" if path is None else path
-    with open(path, "rb") as f:
-        dic = pickle.load(f)
-    to_np = lambda d: {k: {n: np.asarray(a) for n, a in dict(v).items()} for k, v in dict(d).items()}
-    return to_np(dic["params"]), to_np(dic["aux"])
+    dic = load_checkpoint(path)
+    return dic["params"], dic["aux"]
 
 
 def set_duration_model(model) -> None:
@@ -182,17 +180,15 @@ def set_acoustic_model(model) -> None:
 
 def load_acoustic_checkpoint(path=None, with_rng: bool = False):
     """``dic["params"], dic["aux"]`` (and, ``with_rng``, ``dic["rng"]`` as uint32[2]) of ``acoustic_latest_ckpt.pickle``
-    (text2mel.py:62-71)."""
-    import pickle
+    (text2mel.py:62-71); read as :func:`load_duration_checkpoint` reads its file."""
+    from .ckpt import load_checkpoint
 
     path = FLAGS.ckpt_dir / "acoustic_latest_ckpt.pickle" if path is None else path
-    with open(path, "rb") as f:
-        dic = pickle.load(f)
-    to_np = lambda d: {k: {n: np.asarray(a) for n, a in dict(v).items()} for k, v in dict(d).items()}
+    dic = load_checkpoint(path)
     if with_rng:
         rng = dic.get("rng")
-        return to_np(dic["params"]), to_np(dic["aux"]), (None if rng is None else np.asarray(rng).astype(np.uint32).reshape(-1)[-2:])
-    return to_np(dic["params"]), to_np(dic["aux"])
+        return dic["params"], dic["aux"], (None if rng is None else np.asarray(rng).astype(np.uint32).reshape(-1)[-2:])
+    return dic["params"], dic["aux"]
 
 
 def predict_mel(tokens: Sequence[int], durations: np.ndarray, dropout_seed: Optional[int] = 0, dropout_rng=None) -> np.ndarray:
