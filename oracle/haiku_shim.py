@@ -25,7 +25,7 @@ import re
 import sys
 import types
 from collections import namedtuple
-from typing import Any, Dict, List, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 
