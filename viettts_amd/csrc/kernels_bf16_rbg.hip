@@ -35,6 +35,9 @@
 
 #include "bf16_common.h"
 
+#ifndef VTTS_XCD_MAP  // XCD-aware tile order (A/B switch, tools/kbench): see resblock_pair_g_bf16_k
+#define VTTS_XCD_MAP 1
+#endif
 #ifndef VTTS_LEAN  // lean loop addressing (buffer loads with SGPR offsets, per-tap swizzle terms): A/B switch, tools/kbench
 #define VTTS_LEAN 1
 #endif
@@ -90,7 +93,16 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int wn = wave % WN;
     const int l31 = lane & 31;
     const int lh = lane >> 5;
-    const int t0 = blockIdx.x * NT2;         // first output time step of this workgroup
+#if VTTS_XCD_MAP
+    // Workgroups go to the 8 XCDs round-robin in launch order (workgroup w -> XCD w % 8, each with its own L2), so consecutive
+    // blockIdx.x would put every tile's neighbours — whose halo rows it shares — on OTHER L2s.  gridDim.x is padded to a
+    // multiple of 8 and XCD x takes the contiguous tile range [x * per, (x + 1) * per) of each utterance, in order: a tile's
+    // left halo was staged by the same XCD's previous workgroup moments ago.
+    const int tile = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+#else
+    const int tile = blockIdx.x;
+#endif
+    const int t0 = tile * NT2;               // first output time step of this workgroup
     const int b = blockIdx.z;
     const int Lp = a.L;                                      // rows allocated per utterance
     const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
@@ -508,6 +520,9 @@ static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     }
     if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
     dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
+#if VTTS_XCD_MAP
+    grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs; a tile index past the utterance exits at once
+#endif
     hipLaunchKernelGGL(resblock_pair_g_bf16_k<T>, grid, dim3(T::THREADS), T::lds_bytes(a.dil) + VTTS_EXP_LDS_PAD, s, a);
     return hipGetLastError();
 }
