@@ -215,6 +215,27 @@ def test_resblock2_generator_vs_reference_golden(golden_dir, dev):
         Generator(TINY2, device=dev, dtype="bf16")
 
 
+def test_parallel_resblocks_schedule_is_bit_identical(dev):
+    """fp32 engine, small launches: the three ResBlocks of a stage run side by side on parallel streams into separate buffers and
+    are combined afterwards (engine.hip: chains_parallel / mrf_mean_k).  Same additions in the same order as the accumulating
+    epilogues of the one-after-the-other schedule: the samples must be the same BITS, for ResBlock1 and ResBlock2 generators."""
+    from viettts_amd.hifigan.generator import Generator
+
+    for cfg, shapes in ((V1, ((1, 37), (2, 160), (1, 512))), (TINY2, ((2, 12), (1, 300)))):
+        gen = Generator(cfg, device=dev)
+        gen.load_params(synthetic_params(cfg, 4321, "scaled"))
+        for B, T in shapes:
+            mel = torch.from_numpy(synthetic_mel(B, T, 9, cfg.num_mels)).to(dev)
+            gen.set_option("chains", 1)
+            a = gen(mel).clone()
+            a2 = gen(mel).clone()  # twice: the side streams / events are reused
+            gen.set_option("chains", 0)
+            b = gen(mel).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(a, b) and torch.equal(a, a2), (cfg.resblock, B, T, float((a - b).abs().max()))
+        gen.close()
+
+
 def test_baseline_config2_shape(golden_dir, gen_v1, dev):
     """BASELINE config 2: B=1, T=512 fp32, parity <= 1e-4 vs the reference generator."""
     rec = _meta(golden_dir)["v1_scaled_T512"]

@@ -107,6 +107,7 @@ struct vtts_hifigan {
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
     int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
+    int64_t opt_chains = 1;          // fp32, small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // profiling of the dominant kernel class
@@ -564,6 +565,26 @@ int check_pass_size(const vtts_hifigan* h, int B, int T) {
     return VTTS_OK;
 }
 
+// x = (rb_0(x) + rb_1(x) [+ rb_2(x)]) / num_kernels with the ResBlocks' outputs in separate buffers (model.py:115-121): the same
+// additions in the same order as the ACC_STORE / ACC_ADD / ACC_MEAN epilogues (device_common.h), hence the same bits.
+__global__ __launch_bounds__(256) void mrf_mean_k(const float* __restrict__ y0, const float* __restrict__ y1, const float* __restrict__ y2,
+                                                  float* __restrict__ out, size_t n, float div) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = y0[i] + y1[i];
+        if (y2) v = v + y2[i];
+        out[i] = v / div;
+    }
+}
+
+// A single small micro-batch leaves most of the chip idle (B = 1 x T = 512: 256 workgroups of 4 waves in stage 1), and the MRF's
+// ResBlocks of a stage are independent given the stage input: the fp32 engine then runs them on parallel streams into separate
+// buffers and combines them with mrf_mean_k (3 forwards in flight measured 2.2x the time of one: 1.36x the throughput).
+constexpr int PAR_CHAIN_FRAMES = 2048;
+bool chains_parallel(const vtts_hifigan* h, int B, int T) {
+    const int nk = h->cfg.num_kernels;
+    return h->dtype == VTTS_F32 && h->opt_chains && (nk == 2 || nk == 3) && ((long)B * T <= PAR_CHAIN_FRAMES || h->opt_chains == 2) && pick_microbatch(h, B, T) >= B;
+}
+
 struct Taps {
     const char* name = nullptr;
     float* out = nullptr;
@@ -750,6 +771,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
     if (rc0) return rc0;
     const int nk = c.num_kernels;
     const long wav_len = (long)h->hop * T;
+    const bool par = chains_parallel(h, B, T);
 
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int si = (b0 / mb) % nstr;
@@ -759,6 +781,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
         float* bufT = reinterpret_cast<float*>(wsb + 1 * per);   // xt inside a ResBlock pair
         float* bufC = reinterpret_cast<float*>(wsb + 2 * per);   // running x inside a ResBlock
         float* bufS = reinterpret_cast<float*>(wsb + 3 * per);   // MRF accumulator xs / stage output
+        if (par) bufS = reinterpret_cast<float*>(wsb + 1 * per);  // parallel ResBlocks: [X | S | (T, C, Y) per ResBlock] (one micro-batch, si == 0)
         const int nb = std::min(mb, B - b0);
         int rc;
         // conv_pre (model.py:110): mel [nb][T][num_mels] NWC -> S [nb][C0][T]
@@ -783,39 +806,64 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             const long CL = (long)C * L;
             if (tap.name && !strncmp(tap.name, "ups_", 4) && atoi(tap.name + 4) == i)
                 HIP_TRY(hipMemcpyAsync(tap.out + (size_t)b0 * CL, bufX, (size_t)nb * CL * sizeof(float), hipMemcpyDeviceToDevice, s));
-            for (int j = 0; j < nk; ++j) {
+            // one ResBlock of the MRF: X -> (T, C scratch) -> out with the given accumulate mode, on stream cs
+            auto run_chain = [&](int j, float* tT, float* tC, float* out, int mode, float div, hipStream_t cs) -> int {
                 const int base = h->idx_res[i * nk + j];
                 const float* cur = bufX;
+                int rcc = VTTS_OK;
                 if (c.resblock == 2) {
                     // ResBlock2: x = c_z(leaky_relu(x, 0.1)) + x, z = 0, 1 (model.py:69-74); the MRF sum / mean in the last epilogue
-                    for (int z = 0; z < 2; ++z) {
+                    for (int z = 0; z < 2 && !rcc; ++z) {
                         const Layer& cz = h->layers[base + z];
                         if (z == 0) {
-                            rc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, bufC, ACC_STORE, 1.f, 0, nullptr, s);
-                            cur = bufC;
+                            rcc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, tC, ACC_STORE, 1.f, 0, nullptr, cs);
+                            cur = tC;
                         } else {
-                            const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
-                            rc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, bufS, mode, (float)nk, 0, nullptr, s);
+                            rcc = run_layer(h, cz, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, cur, out, mode, div, 0, nullptr, cs);
                         }
-                        if (rc) { (void)join_streams(h, nstr, s0); return rc; }
                     }
-                    continue;
+                    return rcc;
                 }
-                for (int z = 0; z < 3; ++z) {
+                for (int z = 0; z < 3 && !rcc; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
                     const Layer& c2 = h->layers[base + 2 * z + 1];
                     // xt = c1(leaky_relu(x, 0.1))                       (model.py:46-47)
-                    rc = run_layer(h, c1, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, nullptr, bufT, ACC_STORE, 1.f, 0, nullptr, s);
-                    if (rc) { (void)join_streams(h, nstr, s0); return rc; }
+                    rcc = run_layer(h, c1, Act{cur, CL, L, 1}, nb, (int)L, 0.1f, nullptr, tT, ACC_STORE, 1.f, 0, nullptr, cs);
+                    if (rcc) break;
                     // x = c2(leaky_relu(xt, 0.1)) + x                  (model.py:48-50)
                     if (z < 2) {
-                        rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufC, ACC_STORE, 1.f, 0, nullptr, s);
-                        cur = bufC;
+                        rcc = run_layer(h, c2, Act{tT, CL, L, 1}, nb, (int)L, 0.1f, cur, tC, ACC_STORE, 1.f, 0, nullptr, cs);
+                        cur = tC;
                     } else {
-                        // last pair of the ResBlock: fold the MRF sum / mean into the epilogue (model.py:115-121)
-                        const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
-                        rc = run_layer(h, c2, Act{bufT, CL, L, 1}, nb, (int)L, 0.1f, cur, bufS, mode, (float)nk, 0, nullptr, s);
+                        // last pair of the ResBlock: its output (sequential schedule: the MRF sum / mean folded into the epilogue, model.py:115-121)
+                        rcc = run_layer(h, c2, Act{tT, CL, L, 1}, nb, (int)L, 0.1f, cur, out, mode, div, 0, nullptr, cs);
                     }
+                }
+                return rcc;
+            };
+            if (par) {
+                // the ResBlocks side by side on nk streams, each into its own buffers; ((y0 + y1) + y2) / nk afterwards: same additions, same order
+                hipStream_t cs[4];
+                rc = fork_streams(h, nk, s, cs);
+                if (rc) { (void)join_streams(h, nstr, s0); return rc; }
+                float* ys[3] = {nullptr, nullptr, nullptr};
+                for (int j = 0; j < nk; ++j) {
+                    float* cb = reinterpret_cast<float*>(wsb + (size_t)(2 + 3 * j) * per);
+                    float* tT = cb;
+                    float* tC = reinterpret_cast<float*>(wsb + (size_t)(3 + 3 * j) * per);
+                    ys[j] = reinterpret_cast<float*>(wsb + (size_t)(4 + 3 * j) * per);
+                    rc = run_chain(j, tT, tC, ys[j], ACC_STORE, 1.f, cs[j]);
+                    if (rc) { (void)join_streams(h, nk, s); (void)join_streams(h, nstr, s0); return rc; }
+                }
+                rc = join_streams(h, nk, s);
+                if (rc) { (void)join_streams(h, nstr, s0); return rc; }
+                const size_t n = (size_t)nb * CL;
+                hipLaunchKernelGGL(mrf_mean_k, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, ys[0], ys[1], ys[2], bufS, n, (float)nk);
+                if (hipGetLastError() != hipSuccess) { (void)join_streams(h, nstr, s0); return fail(VTTS_ERR_HIP, "mrf_mean launch failed"); }
+            } else {
+                for (int j = 0; j < nk; ++j) {
+                    const int mode = (j == 0) ? ACC_STORE : (j == nk - 1 ? ACC_MEAN : ACC_ADD);
+                    rc = run_chain(j, bufT, bufC, bufS, mode, (float)nk, s);
                     if (rc) { (void)join_streams(h, nstr, s0); return rc; }
                 }
             }
@@ -1049,7 +1097,8 @@ VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, s
     if (int rc = check_pass_size(h, B, T)) return rc;
     const int mb = pick_microbatch(h, B, T);
     const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
-    *bytes = (size_t)num_streams(h, B, T) * 4 * align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
+    const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
+    *bytes = chains_parallel(h, B, T) ? (size_t)(2 + 3 * h->cfg.num_kernels) * per : (size_t)num_streams(h, B, T) * 4 * per;
     return VTTS_OK;
 }
 
@@ -1201,6 +1250,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "streams")) {
         if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
         h->opt_streams = value;
+    } else if (!strcmp(name, "chains")) {
+        if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "chains must be 0 (ResBlocks of a stage one after the other), 1 (side by side on small fp32 launches) or 2 (... on every single-micro-batch launch)");
+        h->opt_chains = value;
     } else if (!strcmp(name, "tiles")) {
         if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "tiles must be 0 (auto), 1 (wide) or 2 (narrow)");
         h->opt_tiles = value;
@@ -1219,6 +1271,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "profile")) *value = h->opt_profile;
     else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
     else if (!strcmp(name, "streams")) *value = h->opt_streams;
+    else if (!strcmp(name, "chains")) *value = h->opt_chains;
     else if (!strcmp(name, "fuse")) *value = h->opt_fuse;
     else if (!strcmp(name, "hop")) *value = h->hop;
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;

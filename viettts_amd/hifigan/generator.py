@@ -131,7 +131,7 @@ class Generator:
     # ---- options --------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
         _lib.check(self.lib, self.lib.vtts_hifigan_set_option(self._h, name.encode(), int(value)))
-        if name in ("microbatch", "streams"):
+        if name in ("microbatch", "streams", "chains"):
             self._ws = None
 
     def get_option(self, name: str) -> int:
