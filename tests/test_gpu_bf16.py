@@ -344,3 +344,93 @@ def test_bf16_benchmark_shape_B64_T1024(golden_dir, dev, capsys):
         assert torch.equal(rag, plain[32:])
     finally:
         gen.close()
+
+
+def test_parallel_resblocks_schedule_is_bit_identical_bf16():
+    """bf16 engine, small launches: the three ResBlocks of a stage on parallel streams with scratch of their own; only a ResBlock's
+    last kernel touches the shared bf16 accumulator and those kernels are chained by events in the sequential order, so every sample
+    sees the same additions and roundings as one-after-the-other.  Same bits: plain, ragged, every fuse level."""
+    from viettts_amd.hifigan.generator import Generator
+
+    dev = torch.device("cuda", 0)
+    gen = Generator(V1, device=dev, dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    for fuse in (2, 1, 0, 3):
+        gen.set_option("fuse", fuse)
+        for B, T in ((1, 37), (2, 160), (1, 512), (3, 97)):
+            mel = torch.from_numpy(synthetic_mel(B, T, 11)).to(dev)
+            outs = {}
+            for mode in (1, 0):
+                gen.set_option("chains", mode)
+                a = gen(mel).clone()
+                a2 = gen(mel).clone()
+                torch.cuda.synchronize()
+                assert torch.equal(a, a2)
+                outs[mode] = a
+            assert torch.equal(outs[1], outs[0]), (fuse, B, T, float((outs[1] - outs[0]).abs().max()))
+    gen.set_option("fuse", 2)
+    mel = torch.from_numpy(synthetic_mel(3, 120, 12)).to(dev)
+    frames = [120, 33, 77]
+    gen.set_option("chains", 1)
+    r1 = gen.forward_ragged(mel, frames).clone()
+    gen.set_option("chains", 0)
+    r0 = gen.forward_ragged(mel, frames).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(r1, r0)
+    gen.close()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_small_launch_graph_replay_is_bit_identical(dtype):
+    """Small launches replay a captured hipGraph from the third call with the same buffers on (engine.hip: forward_maybe_graphed): same
+    bits as the eager path, a graph per (buffers, B, T), dropped when an option or the weight blob changes, and transparent inside a
+    caller's own capture."""
+    from viettts_amd.hifigan.generator import Generator
+
+    dev = torch.device("cuda", 0)
+    gen = Generator(V1, device=dev, dtype=dtype)
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    mel = torch.from_numpy(synthetic_mel(1, 512, 5)).to(dev)
+    mel2 = torch.from_numpy(synthetic_mel(2, 96, 6)).to(dev)
+    out, out2 = torch.empty((1, 256 * 512), device=dev), torch.empty((2, 256 * 96), device=dev)
+    gen.set_option("graph", 0)
+    ref, ref2 = gen(mel, out).clone(), gen(mel2, out2).clone()
+    gen.set_option("graph", 1)
+    assert gen.get_option("graphs_cached") == 0
+    for i in range(20):
+        out.zero_()
+        gen(mel, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), i
+        if i % 2:
+            out2.zero_()
+            gen(mel2, out2)
+            torch.cuda.synchronize()
+            assert torch.equal(out2, ref2), i
+        if i == 5:
+            assert gen.get_option("graphs_cached") == 0  # a few calls do not pay for a capture
+    assert gen.get_option("graphs_cached") == 2  # both keys kept coming back (20 and 10 calls): captured on their 8th
+    for _ in range(2):
+        out2.zero_()
+        gen(mel2, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, ref2) and gen.get_option("graphs_cached") == 2
+    # new data in the same buffers: the graph reads the buffers, not a snapshot
+    mel.copy_(torch.from_numpy(synthetic_mel(1, 512, 77)))
+    gen(mel, out)
+    g_out = out.clone()
+    gen.set_option("graph", 0)  # bumps the epoch: the cached graphs are stale
+    assert torch.equal(gen(mel, out), g_out)
+    gen.set_option("graph", 1)
+    for _ in range(10):
+        gen(mel, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, g_out) and gen.get_option("graphs_cached") >= 1
+    n_before = gen.get_option("graphs_cached")
+    # large launches never go through a graph
+    big = torch.from_numpy(synthetic_mel(8, 1024, 3)).to(dev)
+    ob = torch.empty((8, 256 * 1024), device=dev)
+    for _ in range(10):
+        gen(big, ob)
+    assert gen.get_option("graphs_cached") == n_before
+    gen.close()

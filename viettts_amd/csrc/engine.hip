@@ -107,7 +107,21 @@ struct vtts_hifigan {
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
     int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
-    int64_t opt_chains = 1;          // fp32, small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other)
+    int64_t opt_graph = 1;           // small launches: replay a captured hipGraph once the same buffers were seen twice (0 = always eager)
+    struct GraphEntry {
+        const void* mel = nullptr;
+        void* wav = nullptr;
+        void* ws = nullptr;
+        int B = 0, T = 0, seen = 0;
+        uint64_t epoch = 0, last_use = 0;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+    };
+    std::vector<GraphEntry> graphs;  // at most GRAPH_SLOTS, least recently used evicted
+    hipStream_t cap_stream = nullptr; // launches are recorded on this stream, graphs are launched on the caller's
+    uint64_t epoch = 0, use_clock = 0;  // epoch: bumped by everything a captured launch sequence bakes in (options, the weight blob)
+    int64_t opt_chains = 1;          // small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other, 2 = always)
+    hipEvent_t ev_chain[3] = {nullptr, nullptr, nullptr};  // bf16: ResBlock j's output is in the shared accumulator (orders the accumulating epilogues)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     // profiling of the dominant kernel class
@@ -582,7 +596,13 @@ __global__ __launch_bounds__(256) void mrf_mean_k(const float* __restrict__ y0, 
 constexpr int PAR_CHAIN_FRAMES = 2048;
 bool chains_parallel(const vtts_hifigan* h, int B, int T) {
     const int nk = h->cfg.num_kernels;
-    return h->dtype == VTTS_F32 && h->opt_chains && (nk == 2 || nk == 3) && ((long)B * T <= PAR_CHAIN_FRAMES || h->opt_chains == 2) && pick_microbatch(h, B, T) >= B;
+    if (!h->opt_chains || ((long)B * T > PAR_CHAIN_FRAMES && h->opt_chains != 2) || pick_microbatch(h, B, T) < B) return false;
+    return h->dtype == VTTS_F32 ? (nk == 2 || nk == 3) : (nk == 3 && h->cfg.resblock != 2);
+}
+// workspace buffers of one pass: [X | S | per ResBlock: T, C (, Y: the fp32 engine's separate output)] or the sequential schedule's X, T, C, S
+int pass_buffers(const vtts_hifigan* h, int B, int T) {
+    if (!chains_parallel(h, B, T)) return 4;
+    return 2 + (h->dtype == VTTS_F32 ? 3 : 2) * h->cfg.num_kernels;
 }
 
 struct Taps {
@@ -646,6 +666,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
     if (rc0) return rc0;
     const int nk = c.num_kernels;
     const long wav_len = (long)h->hop * T;
+    const bool par = chains_parallel(h, B, T);
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int si = (b0 / mb) % nstr;
         hipStream_t s = streams[si];
@@ -654,6 +675,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
         char* bufT = wsb + 1 * per;
         char* bufC = wsb + 2 * per;
         char* bufS = wsb + 3 * per;
+        if (par) bufS = wsb + 1 * per;  // parallel ResBlocks: [X | S | (T, C) per ResBlock] (one micro-batch, si == 0)
         const int nb = std::min(mb, B - b0);
         h->cur_b0 = b0;
         int rc;
@@ -679,44 +701,68 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 if (rc) return rc;
             }
             const float next_slope = (i + 1 < c.num_upsamples) ? 0.1f : 0.01f;  // model.py:112 / :122
-            for (int j = 0; j < nk; ++j) {
+            // one ResBlock of the MRF: X -> (tT, tC scratch) -> the shared accumulator S (store / accumulate / accumulate-and-divide in the
+            // LAST kernel's epilogue); `before_last` runs right before that kernel is enqueued (the parallel schedule's ordering point)
+            auto run_chain = [&](int j, char* tT, char* tC, hipStream_t cs, auto before_last) -> int {
                 const int base = h->idx_res[i * nk + j];
                 const char* cur = bufX;
                 const bool last_rb = (j == nk - 1);
+                int rcc;
                 // the whole-ResBlock kernel where it exists and is the faster choice (fuse = 3: wherever it exists)
                 if (h->opt_fuse >= 2 && h->layers[base].has_rb && (h->opt_fuse >= 3 || resblock_bf16_preferred(h->layers[base].cin, h->layers[base].k))) {
                     // the whole ResBlock in one kernel: X -> S (store / accumulate / accumulate-and-divide)
-                    rc = run_resblock_bf16(h, &h->layers[base], cur, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
-                                             last_rb ? (float)nk : 1.0f, s);
-                    if (rc) return rc;
-                    continue;
+                    if ((rcc = before_last())) return rcc;
+                    return run_resblock_bf16(h, &h->layers[base], cur, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
+                                             last_rb ? (float)nk : 1.0f, cs);
                 }
                 if (h->opt_fuse && h->layers[base].has_pair && h->layers[base + 2].has_pair && h->layers[base + 4].has_pair) {
                     // fused pairs cannot run in place (a neighbour tile's halo would see updated rows):
                     // X -> T -> C -> S, with X kept for the other ResBlocks of the stage
-                    rc = run_pair_bf16(h, h->layers[base + 0], cur, nb, (int)L, 1.0f, bufT, 0, 1.f, s);
-                    if (rc) return rc;
-                    rc = run_pair_bf16(h, h->layers[base + 2], bufT, nb, (int)L, 1.0f, bufC, 0, 1.f, s);
-                    if (rc) return rc;
-                    rc = run_pair_bf16(h, h->layers[base + 4], bufC, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
-                                       last_rb ? (float)nk : 1.0f, s);
-                    if (rc) return rc;
-                    continue;
+                    if ((rcc = run_pair_bf16(h, h->layers[base + 0], cur, nb, (int)L, 1.0f, tT, 0, 1.f, cs))) return rcc;
+                    if ((rcc = run_pair_bf16(h, h->layers[base + 2], tT, nb, (int)L, 1.0f, tC, 0, 1.f, cs))) return rcc;
+                    if ((rcc = before_last())) return rcc;
+                    return run_pair_bf16(h, h->layers[base + 4], tC, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
+                                         last_rb ? (float)nk : 1.0f, cs);
                 }
                 for (int z = 0; z < 3; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
                     const Layer& c2 = h->layers[base + 2 * z + 1];
-                    rc = run_layer_bf16(h, c1, cur, C, C, nb, (int)L, 0.1f, 0.1f, nullptr, bufT, 0, 1.f, s);
-                    if (rc) return rc;
+                    if ((rcc = run_layer_bf16(h, c1, cur, C, C, nb, (int)L, 0.1f, 0.1f, nullptr, tT, 0, 1.f, cs))) return rcc;
                     if (z < 2) {
-                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, 1.0f, cur, bufC, 0, 1.f, s);
-                        cur = bufC;
+                        if ((rcc = run_layer_bf16(h, c2, tT, C, C, nb, (int)L, 1.0f, 1.0f, cur, tC, 0, 1.f, cs))) return rcc;
+                        cur = tC;
                     } else {
-                        rc = run_layer_bf16(h, c2, bufT, C, C, nb, (int)L, 1.0f, last_rb ? next_slope : 1.0f, cur, bufS, j > 0 ? 1 : 0,
-                                            last_rb ? (float)nk : 1.0f, s);
+                        if ((rcc = before_last())) return rcc;
+                        if ((rcc = run_layer_bf16(h, c2, tT, C, C, nb, (int)L, 1.0f, last_rb ? next_slope : 1.0f, cur, bufS, j > 0 ? 1 : 0,
+                                                  last_rb ? (float)nk : 1.0f, cs))) return rcc;
                     }
-                    if (rc) return rc;
                 }
+                return VTTS_OK;
+            };
+            if (par) {
+                // The ResBlocks side by side on nk streams with scratch of their own.  Only a ResBlock's LAST kernel touches the shared
+                // accumulator (bf16, rounded after every addition): those kernels are chained by events in the sequential order
+                // rb_0 -> rb_1 -> rb_2, so every sample sees the same additions and roundings as one-after-the-other — the same bits.
+                hipStream_t cs[4];
+                if ((rc = fork_streams(h, nk, s, cs))) return rc;
+                for (int j = 0; j < nk && !rc; ++j) {
+                    char* tT = wsb + (size_t)(2 + 2 * j) * per;
+                    char* tC = wsb + (size_t)(3 + 2 * j) * per;
+                    rc = run_chain(j, tT, tC, cs[j], [&]() -> int {
+                        if (j > 0) HIP_TRY(hipStreamWaitEvent(cs[j], h->ev_chain[j - 1], 0));
+                        return VTTS_OK;
+                    });
+                    if (!rc && j + 1 < nk) {
+                        if (!h->ev_chain[j]) HIP_TRY(hipEventCreateWithFlags(&h->ev_chain[j], hipEventDisableTiming));
+                        HIP_TRY(hipEventRecord(h->ev_chain[j], cs[j]));
+                    }
+                }
+                const int rj = join_streams(h, nk, s);
+                if (rc) return rc;
+                if (rj) return rj;
+            } else {
+                for (int j = 0; j < nk; ++j)
+                    if ((rc = run_chain(j, bufT, bufC, s, []() -> int { return VTTS_OK; }))) return rc;
             }
             if (tap.name && !strncmp(tap.name, "mrf_", 4) && atoi(tap.name + 4) == i) {
                 rc = tap_copy_bf16(bufS, tap.out + (size_t)b0 * CL, (size_t)nb * CL, s);
@@ -936,6 +982,16 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
     return VTTS_OK;
 }
 
+static void drop_graphs(vtts_hifigan* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    h->cap_stream = nullptr;
+}
+
 VTTS_API void vtts_hifigan_destroy(vtts_hifigan* h) {
     if (!h) return;
     for (int i = 0; i < 3; ++i) {
@@ -943,6 +999,9 @@ VTTS_API void vtts_hifigan_destroy(vtts_hifigan* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (hipEvent_t e : h->ev_chain)
+        if (e) (void)hipEventDestroy(e);
+    drop_graphs(h);
     for (auto& p : h->prof_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -1080,6 +1139,7 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
     HIP_TRY(hipMemcpyAsync(dev_blob, host.data(), h->blob_bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));  // `host` dies at return
     h->blob = static_cast<char*>(dev_blob);
+    ++h->epoch;  // captured graphs hold the old blob's addresses
     return VTTS_OK;
 }
 
@@ -1088,6 +1148,7 @@ VTTS_API int vtts_hifigan_bind_packed(vtts_hifigan* h, void* dev_blob, size_t bl
     if (blob_bytes < h->blob_bytes) return fail(VTTS_ERR_NOMEM, "blob too small: %zu < %zu", blob_bytes, h->blob_bytes);
     if ((reinterpret_cast<uintptr_t>(dev_blob) & 255) != 0) return fail(VTTS_ERR_INVALID, "blob must be 256-B aligned");
     h->blob = static_cast<char*>(dev_blob);
+    ++h->epoch;  // captured graphs hold the old blob's addresses
     return VTTS_OK;
 }
 
@@ -1098,14 +1159,92 @@ VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, s
     const int mb = pick_microbatch(h, B, T);
     const size_t es = h->dtype == VTTS_BF16 ? 2 : sizeof(float);
     const size_t per = align_up(max_act_elems(h, T) * (size_t)mb * es, 256);
-    *bytes = chains_parallel(h, B, T) ? (size_t)(2 + 3 * h->cfg.num_kernels) * per : (size_t)num_streams(h, B, T) * 4 * per;
+    *bytes = chains_parallel(h, B, T) ? (size_t)pass_buffers(h, B, T) * per : (size_t)num_streams(h, B, T) * 4 * per;
     return VTTS_OK;
+}
+
+// Small launches are a chain of ~40 short kernels over up to three streams; replaying them as ONE hipGraph removes the host's
+// launch / event calls and the cross-stream waits from the critical path (bf16, one 512-frame utterance: 0.81 -> 0.70 ms).  A graph
+// bakes in every pointer, so it is keyed by (mel, wav, workspace, B, T) and by an epoch that options and the weight blob bump; it is
+// captured the GRAPH_AFTER-th time the same key shows up (the eager runs before it also finish every lazy initialisation: side
+// streams, events, function attributes), replayed afterwards, and anything unexpected falls back to the eager path.
+constexpr int GRAPH_SLOTS = 8;
+constexpr int GRAPH_AFTER = 8;  // capture + instantiate cost about a millisecond, once: only a key that keeps coming back pays it
+int forward_maybe_graphed(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, size_t ws_bytes, hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (!h->opt_graph || h->opt_profile || B <= 0 || T <= 0 || !h->blob || !chains_parallel(h, B, T) ||
+        hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone)  // inside the CALLER's capture: just enqueue
+        return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    vtts_hifigan::GraphEntry* e = nullptr;
+    for (auto& g : h->graphs)
+        if (g.mel == mel && g.wav == wav && g.ws == ws && g.B == B && g.T == T) e = &g;
+    if (e && e->epoch != h->epoch) {  // stale: start over
+        if (e->exec) (void)hipGraphExecDestroy(e->exec);
+        if (e->graph) (void)hipGraphDestroy(e->graph);
+        e->exec = nullptr;
+        e->graph = nullptr;
+        e->seen = 0;
+        e->epoch = h->epoch;
+    }
+    if (!e) {
+        if ((int)h->graphs.size() < GRAPH_SLOTS) {
+            h->graphs.emplace_back();
+            e = &h->graphs.back();
+        } else {
+            e = &h->graphs[0];
+            for (auto& g : h->graphs)
+                if (g.last_use < e->last_use) e = &g;
+            if (e->exec) (void)hipGraphExecDestroy(e->exec);
+            if (e->graph) (void)hipGraphDestroy(e->graph);
+        }
+        *e = vtts_hifigan::GraphEntry{};
+        e->mel = mel; e->wav = wav; e->ws = ws; e->B = B; e->T = T; e->epoch = h->epoch;
+    }
+    e->last_use = ++h->use_clock;
+    if (e->exec) {
+        hipError_t le = hipGraphLaunch(e->exec, s);
+        if (le == hipSuccess) return VTTS_OK;
+        (void)hipGetLastError();
+        e->seen = -1;  // never again for this key
+        (void)hipGraphExecDestroy(e->exec);
+        e->exec = nullptr;
+        return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    }
+    if (e->seen < 0 || ++e->seen < GRAPH_AFTER) return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    // a key that keeps coming back: record this call's launches into a graph (on a stream of the handle's own: the caller's may be the legacy
+    // default stream, which cannot be captured), then launch the graph on the caller's stream
+    if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        h->cap_stream = nullptr;
+        e->seen = -1;
+        return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    }
+    if (hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        e->seen = -1;
+        return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    }
+    const int rc = forward_impl(h, mel, B, T, wav, ws, ws_bytes, h->cap_stream, Taps{});
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(h->cap_stream, &g);
+    hipGraphExec_t ex = nullptr;
+    if (rc == VTTS_OK && ce == hipSuccess && g && hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess && hipGraphLaunch(ex, s) == hipSuccess) {
+        e->graph = g;
+        e->exec = ex;
+        return VTTS_OK;
+    }
+    (void)hipGetLastError();
+    if (ex) (void)hipGraphExecDestroy(ex);
+    if (g) (void)hipGraphDestroy(g);
+    e->seen = -1;
+    if (rc) return rc;  // the enqueue itself failed: report that
+    return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});  // nothing ran during the capture: run it now
 }
 
 VTTS_API int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, float* wav_dev, void* workspace,
                                   size_t workspace_bytes, vtts_stream stream) {
     if (!h || !mel_dev || !wav_dev) return fail(VTTS_ERR_INVALID, "null argument");
-    return forward_impl(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream), Taps{});
+    return forward_maybe_graphed(h, mel_dev, B, T, wav_dev, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 VTTS_API int vtts_hifigan_forward_ragged(vtts_hifigan* h, const float* mel_dev, const int32_t* frames_dev, int B, int T, float* wav_dev,
@@ -1238,6 +1377,7 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
 
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
+    ++h->epoch;  // a captured launch sequence reflects the options it was captured under
     if (!strcmp(name, "kernels")) {
         if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "kernels must be 0 (auto) or 1 (generic)");
         h->opt_kernels = value;
@@ -1250,6 +1390,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "streams")) {
         if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
         h->opt_streams = value;
+    } else if (!strcmp(name, "graph")) {
+        if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "graph must be 0 (always eager) or 1 (small launches replay a captured hipGraph)");
+        h->opt_graph = value;
     } else if (!strcmp(name, "chains")) {
         if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "chains must be 0 (ResBlocks of a stage one after the other), 1 (side by side on small fp32 launches) or 2 (... on every single-micro-batch launch)");
         h->opt_chains = value;
@@ -1272,6 +1415,11 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
     else if (!strcmp(name, "streams")) *value = h->opt_streams;
     else if (!strcmp(name, "chains")) *value = h->opt_chains;
+    else if (!strcmp(name, "graph")) *value = h->opt_graph;
+    else if (!strcmp(name, "graphs_cached")) {
+        *value = 0;
+        for (auto& g : h->graphs) *value += g.exec ? 1 : 0;
+    }
     else if (!strcmp(name, "fuse")) *value = h->opt_fuse;
     else if (!strcmp(name, "hop")) *value = h->hop;
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;

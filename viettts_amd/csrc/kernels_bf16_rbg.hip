@@ -44,6 +44,8 @@
 
 namespace vtts {
 
+constexpr int XCD_MAP_MIN_TILES = 192;  // XCD-aware tile order from this many tiles per utterance slot on (resblock_pair_g_bf16_k)
+
 template <int C_, int KS_, int N1_, int WM_, int WN_, int PA_, int MINWG_, int XC_ = C_>
 struct GTile {
     static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, PA = PA_, MINWG = MINWG_;
@@ -93,19 +95,27 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int wn = wave % WN;
     const int l31 = lane & 31;
     const int lh = lane >> 5;
+    const int b = blockIdx.z;
+    const int Lp = a.L;                                      // rows allocated per utterance
+    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
 #if VTTS_XCD_MAP
     // Workgroups go to the 8 XCDs round-robin in launch order (workgroup w -> XCD w % 8, each with its own L2), so consecutive
     // blockIdx.x would put every tile's neighbours — whose halo rows it shares — on OTHER L2s.  gridDim.x is padded to a
-    // multiple of 8 and XCD x takes the contiguous tile range [x * per, (x + 1) * per) of each utterance, in order: a tile's
-    // left halo was staged by the same XCD's previous workgroup moments ago.
-    const int tile = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // multiple of 8 and an XCD takes a contiguous eighth of THIS utterance's valid tiles, in order (a tile's left halo was staged by
+    // the same XCD's previous workgroup moments ago).  Eighths of the VALID tiles, balanced to within one tile and rotated from
+    // utterance to utterance: with ceil(nt / 8) per XCD a batch of short utterances (nt = 9: 2, 2, 2, 2, 1, 0, 0, 0) left the
+    // same XCDs idle for every utterance (+4 % on the 256-sentence pipeline).
+    // Only launches whose utterance slots hold at least XCD_MAP_MIN_TILES tiles do this (the launcher pads gridDim.x for exactly those):
+    // with a few tiles per eighth the saving is small, and a padded grid sends tile t of EVERY utterance to XCD t % 8, which on the
+    // 256-sentence pipeline (15-140 tiles per utterance and stage) left the last XCDs a tile short per utterance: 2-4 % slower.
+    const bool xmap = (a.L + NT2 - 1) / NT2 >= XCD_MAP_MIN_TILES;
+    const int nt = (L + NT2 - 1) / NT2, r = (int)((blockIdx.x + b) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
+    const int tile = xmap ? lo + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (xmap && tile >= hi) return;
 #else
     const int tile = blockIdx.x;
 #endif
     const int t0 = tile * NT2;               // first output time step of this workgroup
-    const int b = blockIdx.z;
-    const int Lp = a.L;                                      // rows allocated per utterance
-    const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
     if (t0 >= L) return;                                     // a tile past this utterance's end: nothing reads its rows
     const int dil = a.dil;
     const int h1 = H2 * dil;                 // c1's symmetric pad (model.py:8-10)
@@ -521,7 +531,7 @@ static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
     dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
 #if VTTS_XCD_MAP
-    grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs; a tile index past the utterance exits at once
+    if ((int)grid.x >= XCD_MAP_MIN_TILES) grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs; a tile index past the utterance exits at once
 #endif
     hipLaunchKernelGGL(resblock_pair_g_bf16_k<T>, grid, dim3(T::THREADS), T::lds_bytes(a.dil) + VTTS_EXP_LDS_PAD, s, a);
     return hipGetLastError();

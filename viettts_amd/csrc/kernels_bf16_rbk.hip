@@ -77,9 +77,13 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int d0 = a.dils[0], d1 = a.dils[1], d2 = a.dils[2];
     const int M = H * (d0 + d1 + d2) + 3 * H;  // invalid margin per side after the three pairs
     const int NT = W - 2 * M;                  // outputs per workgroup
-    // XCD-aware tile order (as resblock_pair_g_bf16_k, kernels_bf16_rbg.hip): gridDim.x is a multiple of 8 and XCD x (= workgroup
-    // index % 8) takes a contiguous range of the utterance's windows, so the 2 * M margin rows shared with the previous window are L2 hits
-    const int tile = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    // XCD-aware tile order (as resblock_pair_g_bf16_k, kernels_bf16_rbg.hip): gridDim.x is a multiple of 8 and an XCD (= workgroup index % 8)
+    // takes a contiguous, balanced eighth of the utterance's VALID windows (rotated per utterance): the 2 * M margin rows shared with the
+    // previous window are L2 hits
+    const int ntv = (L + NT - 1) / NT, rx = (int)((blockIdx.x + b) & 7), lox = (rx * ntv) >> 3, hix = ((rx + 1) * ntv) >> 3;
+    const bool xmap = (a.L + NT - 1) / NT >= 192;  // launches of short utterance slots keep the launch order (kernels_bf16_rbg.hip: XCD_MAP_MIN_TILES)
+    const int tile = xmap ? lox + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (xmap && tile >= hix) return;
     const int t0 = tile * NT;                  // first output time step
     if (t0 >= L) return;                       // a tile past this utterance's end
     const int tw = t0 - M;                     // time of window row 0
@@ -382,7 +386,8 @@ static hipError_t launch_rb(const BConvArgs& a, hipStream_t s) {
     }
     const int NT = T::W - 2 * (T::H * dsum + 3 * T::H);
     if (NT < 32) return hipErrorInvalidValue;
-    dim3 grid(((a.L + NT - 1) / NT + 7) / 8 * 8, 1, a.B);  // whole rounds of the 8 XCDs; a window past the utterance exits at once
+    dim3 grid((a.L + NT - 1) / NT, 1, a.B);
+    if ((int)grid.x >= 192) grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs (XCD-aware order); a window past the utterance exits at once
     hipLaunchKernelGGL(resblock_bf16_k<T>, grid, dim3(T::THREADS), T::LDS_BYTES, s, a);
     return hipGetLastError();
 }
