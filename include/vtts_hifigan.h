@@ -179,10 +179,15 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
  *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another
- *   "chains"    fp32: 1 (default) = on a small single-micro-batch launch (B * T <= 2048 frames) the ResBlocks of a stage run side
- *               by side on parallel streams into separate buffers and are combined afterwards — the same additions in the same
- *               order, bit-identical samples, 3.7 instead of 4.6 ms for one 512-frame utterance; 0 = one after the other;
- *               2 = side by side on every single-micro-batch launch.  workspace_bytes() depends on it.
+ *   "chains"    1 (default) = on a small single-micro-batch launch (B * T <= 2048 frames) the ResBlocks of a stage run side by side on
+ *               parallel streams with scratch of their own: the fp32 engine combines their outputs afterwards, the bf16 engine chains the
+ *               accumulating epilogues by events in the sequential order — the same additions (and bf16 roundings) in the same
+ *               order, bit-identical samples; 0 = one after the other; 2 = side by side on every single-micro-batch launch.
+ *               workspace_bytes() depends on it.
+ *   "graph"     1 (default) = a small launch (as above) whose (mel, wav, workspace, B, T) came back 8 times is captured into a hipGraph
+ *               and replayed from then on (about a millisecond once, then no host launch / event calls in the latency path: one 512-frame
+ *               utterance 0.81 -> 0.69 ms bf16, 4.57 -> 3.65 ms fp32 together with "chains"); dropped when an option or the weight
+ *               blob changes; inside a caller's own stream capture the launches are simply enqueued.  0 = always eager.
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
  *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
  */
