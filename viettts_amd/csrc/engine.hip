@@ -1171,11 +1171,11 @@ VTTS_API int vtts_hifigan_workspace_bytes(const vtts_hifigan* h, int B, int T, s
 constexpr int GRAPH_SLOTS = 8;
 constexpr int GRAPH_AFTER = 8;  // capture + instantiate cost about a millisecond, once: only a key that keeps coming back pays it
 int forward_maybe_graphed(vtts_hifigan* h, const float* mel, int B, int T, float* wav, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (hipSetDevice(h->device) != hipSuccess) return fail(VTTS_ERR_HIP, "hipSetDevice(%d) failed", h->device);  // graph launches too run on THIS handle's device
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (!h->opt_graph || h->opt_profile || B <= 0 || T <= 0 || !h->blob || !chains_parallel(h, B, T) ||
         hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone)  // inside the CALLER's capture: just enqueue
         return forward_impl(h, mel, B, T, wav, ws, ws_bytes, s, Taps{});
+    if (hipSetDevice(h->device) != hipSuccess) return fail(VTTS_ERR_HIP, "hipSetDevice(%d) failed", h->device);  // graph launches too run on THIS handle's device
     vtts_hifigan::GraphEntry* e = nullptr;
     for (auto& g : h->graphs)
         if (g.mel == mel && g.wav == wav && g.ws == ws && g.B == B && g.T == T) e = &g;
