@@ -456,9 +456,19 @@ def main():
                 torch.cuda.synchronize()
                 lat.append(time.perf_counter() - t1)
             med = statistics.median(lat)
+            gen.set_option("graph", 0)  # the same call with every launch enqueued by the host (no hipGraph replay)
+            lat_e = []
+            for _ in range(10):
+                t1 = time.perf_counter()
+                gen(m1, o1)
+                torch.cuda.synchronize()
+                lat_e.append(time.perf_counter() - t1)
+            gen.set_option("graph", 1)
             res["rtf_b1"] = {
-                "workload": "B=1, T=512 frames (131072 samples)",
+                "workload": "B=1, T=512 frames (131072 samples), the same device buffers every call (steady-state serving): the stage's ResBlocks "
+                            "run on parallel streams and, from the 8th call on, the library replays the hipGraph it captured",
                 "latency_ms": med * 1e3,
+                "latency_ms_eager_launches": statistics.median(lat_e) * 1e3,
                 "rtf_16000": med / (131072 / 16000.0),
                 "rtf_22050": med / (131072 / 22050.0),
                 "samples_per_s": 131072 / med,
