@@ -267,6 +267,7 @@ def main():
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 side measurement")
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="micro-batches in flight on separate HIP streams (0 = engine default)")
+    ap.add_argument("--chains", type=int, default=-1, help="engine option 'chains' (0 / 1 / 2; -1 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
@@ -299,6 +300,8 @@ def main():
         gen.set_option("microbatch", args.microbatch)
     if args.streams:
         gen.set_option("streams", args.streams)
+    if args.chains >= 0:
+        gen.set_option("chains", args.chains)
     bstats = {}
     vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info, bstats)
 
