@@ -31,6 +31,7 @@ REPO = Path(__file__).resolve().parents[1]
 REF = Path("/root/reference")
 OUT = Path(os.environ.get("VTTS_NAT_GOLDEN_OUT") or REPO / "tests" / "golden" / "nat_text2mel_golden.npz")  # the override: tests re-mint into a scratch file
 RNG_KEY = np.array([0x1234ABCD, 0x0F1E2D3C], dtype=np.uint32)  # the synthetic checkpoint's `rng`
+FRAME_SILENCE = 0.2  # --silence-duration of the whole-transcript frame-count table
 CASES = [  # (transcript line index, silence_duration)
     (0, -1.0),
     (3, 0.2),
@@ -123,6 +124,30 @@ def main() -> int:
                 out[p + "trailing_frames"] = np.array(a["trail"])
                 out[p + "mel_full"] = a["mel_full"][0].astype(np.float64)
                 out[p + "mel_fp32run_maxabs"] = np.array(err32)
+            # ---- integer frame counts of the WHOLE demo transcript (BASELINE: "bit-exact for the NAT duration model's integer frame counts"):
+            # every line through the reference's text2tokens + predict_duration + the rules of text2mel.py:88-102, float32 as the
+            # reference computes and float64 as a margin check
+            allc = {k: [] for k in ("n32", "n64", "t32", "t64", "frac64", "tfrac64", "ntok")}
+            for text in lines:
+                per = {}
+                for dt in (np.float64, np.float32):
+                    shim.set_dtype(dt)
+                    tokens = ref_t2m.text2tokens(text, lexicon)
+                    dur = ref_t2m.predict_duration(tokens)
+                    d2 = np.where(np.array(tokens)[None, :] == ref_t2m.FLAGS.sil_index, np.clip(dur, FRAME_SILENCE, None), dur)
+                    d2 = np.where(np.array(tokens)[None, :] == ref_t2m.FLAGS.word_end_index, 0.0, d2).astype(dt)
+                    frames = d2 * ref_t2m.FLAGS.sample_rate / (ref_t2m.FLAGS.n_fft // 4)
+                    tsec = d2[0, -1].item() * ref_t2m.FLAGS.sample_rate / (ref_t2m.FLAGS.n_fft // 4) if tokens[-1] == ref_t2m.FLAGS.sil_index else 0.0
+                    per[dt] = (int(np.sum(frames).item()), int(tsec), float(np.sum(frames)) % 1.0, float(tsec) % 1.0, len(tokens))
+                allc["n64"].append(per[np.float64][0]); allc["t64"].append(per[np.float64][1])
+                allc["n32"].append(per[np.float32][0]); allc["t32"].append(per[np.float32][1])
+                allc["frac64"].append(per[np.float64][2]); allc["tfrac64"].append(per[np.float64][3]); allc["ntok"].append(per[np.float64][4])
+            out["all_silence_duration"] = np.array(FRAME_SILENCE)
+            out["all_n_frames_f32"] = np.array(allc["n32"]); out["all_n_frames_f64"] = np.array(allc["n64"])
+            out["all_trailing_f32"] = np.array(allc["t32"]); out["all_trailing_f64"] = np.array(allc["t64"])
+            out["all_frac_f64"] = np.array(allc["frac64"]); out["all_trailing_frac_f64"] = np.array(allc["tfrac64"]); out["all_n_tokens"] = np.array(allc["ntok"])
+            same = int(np.sum((out["all_n_frames_f32"] == out["all_n_frames_f64"]) & (out["all_trailing_f32"] == out["all_trailing_f64"])))
+            print(f"all {len(lines)} transcript lines at silence {FRAME_SILENCE}: {int(out['all_n_frames_f32'].sum())} frames; float32 and float64 runs agree on {same} lines")
         finally:
             os.chdir(cwd)
     np.savez_compressed(OUT, **out)
