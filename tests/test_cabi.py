@@ -114,3 +114,29 @@ def test_product_path_has_no_cpu_fallback():
     for p in (REPO / "viettts_amd").rglob("*.py"):
         src = p.read_text()
         assert "import oracle" not in src and "from oracle" not in src, p
+
+
+def test_integration_md_stub_matches_the_abi(lib):
+    """INTEGRATION.md §3 (the binding a maintainer of vietTTS/hifigan/mel2wave.py:20-41 would add): its struct is the header's
+    struct — same fields, order, types, size — and every entry point it calls is exported.  (Round 2's document was one
+    `int32_t resblock` short of ABI v2.)  The block is EXECUTED on the GPU by tests/test_gpu_parity.py."""
+    import ast
+
+    from _integration_stub import stub_source
+
+    src = stub_source()
+    tree = ast.parse(src)  # compiles
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "_Cfg"][0]
+    ns = {"C": C}
+    exec(compile(ast.Module([cls], []), "INTEGRATION.md", "exec"), ns)
+    doc = ns["_Cfg"]
+    assert [f[0] for f in doc._fields_] == [f[0] for f in _lib.CfgStruct._fields_]
+    assert C.sizeof(doc) == C.sizeof(_lib.CfgStruct)
+    for (_, a), (_, b) in zip(doc._fields_, _lib.CfgStruct._fields_):
+        assert C.sizeof(a) == C.sizeof(b)
+    # the header's own field list, parsed
+    header = (REPO / "include" / "vtts_hifigan.h").read_text()
+    body = header[header.index("typedef struct vtts_hifigan_cfg {") : header.index("} vtts_hifigan_cfg;")]
+    assert re.findall(r"int32_t\s+([a-z_]+)", body) == [f[0] for f in doc._fields_]
+    for sym in set(re.findall(r"_lib\.(vtts_[a-z_0-9]+)", src)):
+        assert hasattr(lib, sym), sym

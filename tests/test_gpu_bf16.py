@@ -434,3 +434,63 @@ def test_small_launch_graph_replay_is_bit_identical(dtype):
         gen(big, ob)
     assert gen.get_option("graphs_cached") == n_before
     gen.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Edge lengths against the ORACLE (not against the engine itself): utterances shorter than every halo, where every tile
+# is an edge tile and takes the clamped / masked staging path (kernels_bf16_rbg.hip stage_x, kernels_bf16_rbk.hip) and
+# the reference's zero padding (vietTTS/hifigan/model.py:8-10 get_padding, :109-125 Generator.__call__) decides most
+# samples.  Same bounds as the benchmark-shape tests above (BF16_MAXABS on the waveform, BF16_SNR_DB on the pre-tanh
+# signal), every `fuse` setting, both fused-pair tile widths (option "tiles": 1 wide, 2 narrow).
+# ------------------------------------------------------------------------------------------------------------------
+EDGE_FRAMES = [1, 2, 3, 4, 5, 13]
+
+
+@pytest.fixture(scope="module")
+def edge_oracle(v1_params):
+    """fp64 oracle output (waveform, pre-tanh) of one seeded mel per edge length."""
+    out = {}
+    for T in EDGE_FRAMES:
+        mel = synthetic_mel(1, T, 900 + T)
+        y, pre = orc.generator_forward(v1_params, mel, V1, np.float64, return_pre_tanh=True)
+        out[T] = (mel, y[0, :, 0], pre[0, :, 0])
+    return out
+
+
+def _edge_check(wav, pre, want_y, want_pre, what):
+    e_y = float(np.abs(wav.astype(np.float64) - want_y).max())
+    snr = float(10 * np.log10((want_pre ** 2).mean() / ((pre.astype(np.float64) - want_pre) ** 2).mean()))
+    assert np.isfinite(wav).all() and e_y < BF16_MAXABS and snr > BF16_SNR_DB, (what, e_y, snr)
+    return e_y, snr
+
+
+@pytest.mark.parametrize("tiles", [1, 2], ids=["wide-tiles", "narrow-tiles"])
+@pytest.mark.parametrize("fuse", [3, 2, 1, 0], ids=["fused-resblocks-all", "fused-resblocks", "fused-pairs", "per-conv"])
+def test_bf16_edge_lengths_vs_oracle(gen, dev, edge_oracle, capsys, fuse, tiles):
+    gen.set_option("fuse", fuse)
+    gen.set_option("tiles", tiles)
+    worst = (0.0, 1e9)
+    try:
+        for T in EDGE_FRAMES:
+            mel, want_y, want_pre = edge_oracle[T]
+            wav, pre = gen.forward_tap(torch.from_numpy(mel).to(dev), "pre_tanh")
+            torch.cuda.synchronize()
+            e_y, snr = _edge_check(wav.cpu().numpy()[0], pre.cpu().numpy()[0], want_y, want_pre, ("alone", T, fuse, tiles))
+            worst = (max(worst[0], e_y), min(worst[1], snr))
+        # the same utterances as rows of ONE ragged batch (vtts_hifigan_forward_ragged): each row against the oracle's
+        # output for that utterance alone, the rest of the slot zero
+        Tmax = max(EDGE_FRAMES)
+        batch = np.full((len(EDGE_FRAMES), Tmax, V1.num_mels), 77.0, np.float32)  # whatever sits past an utterance's end must not matter
+        for b, T in enumerate(EDGE_FRAMES):
+            batch[b, :T] = edge_oracle[T][0][0]
+        got = gen.forward_ragged(torch.from_numpy(batch).to(dev), EDGE_FRAMES).cpu().numpy()
+        for b, T in enumerate(EDGE_FRAMES):
+            want_y = edge_oracle[T][1]
+            e_y = float(np.abs(got[b, : 256 * T].astype(np.float64) - want_y).max())
+            assert e_y < BF16_MAXABS, ("ragged row", T, fuse, tiles, e_y)
+            assert not got[b, 256 * T :].any()
+    finally:
+        gen.set_option("fuse", 2)
+        gen.set_option("tiles", 0)
+    with capsys.disabled():
+        print(f"\n[bf16 edge lengths vs fp64 oracle, fuse={fuse} tiles={tiles}] worst max|dy| {worst[0]:.2e}, worst SNR {worst[1]:.1f} dB")

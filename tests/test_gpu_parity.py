@@ -362,3 +362,34 @@ def test_mel2wave_dropin(tmp_path, monkeypatch, v1_params, dev):
     assert chunked.shape == one_shot.shape == (256 * 9000,)
     assert np.abs(chunked - one_shot).max() < 5e-6
     m2w.reload()
+
+
+def test_integration_md_stub_executes(tmp_path, monkeypatch, v1_params, dev):
+    """The ctypes stub of INTEGRATION.md §3 — what a maintainer would put in place of vietTTS/hifigan/mel2wave.py:20-41 — run as
+    written (library path made absolute, the reference's FLAGS import replaced: tests/_integration_stub.py) against a scratch
+    assets/ tree; its waveform is the product's `mel2wave` output (same engine, same weights: bit for bit) and meets the fp32 bar
+    against the oracle."""
+    from _integration_stub import runnable_source
+    from viettts_amd import _lib
+    from viettts_amd.hifigan import mel2wave as m2w
+    from viettts_amd.hifigan.weights import save_haiku_pickle
+
+    (tmp_path / "assets/hifigan").mkdir(parents=True)
+    (tmp_path / "assets/infore/hifigan").mkdir(parents=True)
+    repo_cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets/hifigan/config.json")
+    (tmp_path / "assets/hifigan/config.json").write_text(open(repo_cfg).read())
+    save_haiku_pickle(tmp_path / "assets/infore/hifigan/hk_hifi.pickle", v1_params)
+    monkeypatch.chdir(tmp_path)
+    _lib.load()  # the process's HIP runtime is already global; the stub's own CDLL calls find the same objects
+    ns = {"__name__": "integration_md_stub"}
+    exec(compile(runnable_source(str(_lib.default_lib_path()), str(tmp_path / "assets/infore/hifigan")), "INTEGRATION.md", "exec"), ns)
+    mel = synthetic_mel(2, 12, 5)
+    got = ns["mel2wave"](mel)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == (2, 12 * 256)
+    m2w.reload()
+    want = m2w.mel2wave(mel)
+    m2w.reload()
+    assert np.array_equal(got, want)
+    assert np.abs(got - orc.mel2wave_oracle(v1_params, mel, V1)).max() < TIGHT
+    one = ns["mel2wave"](synthetic_mel(1, 7, 6))
+    assert one.shape == (7 * 256,)

@@ -491,6 +491,7 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     a.slope_out = slope_out;
     a.acc_add = acc_add;
     a.div = div;
+    a.tile_pref = (int)h->opt_tiles;
     const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
     if (prof) {
         if (h->prof_used == h->prof_events.size()) {

@@ -548,11 +548,13 @@ static hipError_t launch_g_ks(const BConvArgs& a, int K, hipStream_t s) {
 }
 
 hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
+    // narrow tiles for small launches (a.tile_pref: 1 forces the wide tile, 2 the narrow one)
+    auto narrow = [&](int nt2) { return a.tile_pref == 2 || (a.tile_pref != 1 && (long)((a.L + nt2 - 1) / nt2) * a.B < G_MIN_WGS); };
     switch (C) {
-        case 256: return (long)((a.L + G256<11>::NT2 - 1) / G256<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G256S>(a, K, s) : launch_g_ks<G256>(a, K, s);
-        case 128: return (long)((a.L + G128<11>::NT2 - 1) / G128<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G128S>(a, K, s) : launch_g_ks<G128>(a, K, s);
-        case 64: return (long)((a.L + G64<11>::NT2 - 1) / G64<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G64S>(a, K, s) : launch_g_ks<G64>(a, K, s);
-        case 32: return (long)((a.L + G32<11>::NT2 - 1) / G32<11>::NT2) * a.B < G_MIN_WGS ? launch_g_ks<G32S>(a, K, s) : launch_g_ks<G32>(a, K, s);
+        case 256: return narrow(G256<11>::NT2) ? launch_g_ks<G256S>(a, K, s) : launch_g_ks<G256>(a, K, s);
+        case 128: return narrow(G128<11>::NT2) ? launch_g_ks<G128S>(a, K, s) : launch_g_ks<G128>(a, K, s);
+        case 64: return narrow(G64<11>::NT2) ? launch_g_ks<G64S>(a, K, s) : launch_g_ks<G64>(a, K, s);
+        case 32: return narrow(G32<11>::NT2) ? launch_g_ks<G32S>(a, K, s) : launch_g_ks<G32>(a, K, s);
     }
     return hipErrorInvalidValue;
 }
