@@ -187,20 +187,43 @@ def parity_bf16(gen, dev):
     return out
 
 
-def pmc_traffic(kernel: str, args, B: int, T: int):
-    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside a run (and never in the
-    same pass as a timed measurement): the number comes from the committed rocprofv3 --pmc passes of this same command
-    (profiles/traffic_<dtype>.json names them) and is reported only when kernel and launch problem match."""
-    path = os.path.join(REPO, "profiles", f"traffic_{args.dtype}.json")
+def pmc_counters(kernel: str, args, B: int, T: int):
+    """Counter-derived numbers for the roofline object: HBM bytes per launch of the dominant kernel (`traffic`) and MFMA
+    utilisation (dominant kernel; time-weighted over all ResBlock kernels).  PMC counters cannot be read from inside a run (and
+    never in the same pass as a timed measurement): they come from the committed rocprofv3 passes of THIS command on THIS build —
+    `tools/profile_final.sh` -> `profiles/counters_bf16.json`, which records the digest of the sources it profiled — and are
+    reported only while that digest equals the digest of the sources the loaded library was built from (its build stamp) and
+    kernel and launch problem match.  Otherwise: None plus the reason."""
+    path = os.path.join(REPO, "profiles", f"counters_{args.dtype}.json")
     try:
         with open(path) as f:
             rec = json.load(f)
     except OSError:
-        return None
-    if rec.get("kernel") != kernel or (B, T) != (64, 1024) or args.microbatch not in (0, 64):
-        return None
-    return {"hbm_bytes_per_launch": rec["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": rec["algorithmic_bytes_per_launch"],
-            "source": rec["source"]}
+        return None, None, f"profiles/counters_{args.dtype}.json absent"
+    from viettts_amd import _lib
+    from viettts_amd.csrc.build import _digest
+
+    stamp_file = str(_lib.default_lib_path()) + ".sha256"
+    try:
+        with open(stamp_file) as f:
+            stamp = f.read().strip()
+    except OSError:
+        stamp = None
+    if stamp is None or stamp != _digest():
+        return None, None, "the loaded library's build stamp does not match the sources in the tree"
+    if rec.get("source_digest") != stamp:
+        return None, None, f"profiles/counters_{args.dtype}.json was measured on another build ({str(rec.get('source_digest'))[:12]} vs {stamp[:12]})"
+    if (B, T) != (64, 1024) or args.microbatch not in (0, 64):
+        return None, None, "counters were collected at B=64 x T=1024 only"
+    hit = [(k, v) for k, v in rec["kernels"].items() if k.startswith(kernel)]
+    if len(hit) != 1:
+        return None, None, f"kernel {kernel!r} not in the counter file"
+    k = hit[0][1]
+    traffic = k["hbm_read_bytes"] + k["hbm_write_bytes"] if k.get("hbm_read_bytes") else None
+    util = {"dominant_kernel": k.get("mfma_util"), "time_weighted_resblock_kernels": rec.get("time_weighted_mfma_util_resblock_kernels"),
+            "lds_bank_conflict_cycles_dominant": k.get("lds_bank_conflict_cycles"),
+            "source": f"profiles/{rec.get('tag')}_pmc.md, profiles/{rec.get('tag')}_kernel_stats.md (source digest {stamp[:16]})"}
+    return traffic, util, None
 
 
 def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None):
@@ -428,13 +451,17 @@ def main():
         # ---- roofline of the dominant kernel, HIP events on the launch stream, timed region only ----
         if prof["launches"] > 0 and prof["ms"] > 0:
             ach = prof["flops"] / (prof["ms"] * 1e-3) / 1e12
+            traffic, util, why_not = pmc_counters(prof["kernel"], args, B, T)
             res["roofline"] = {
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": PEAK_TFLOPS[args.dtype],
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.dtype],
-                "traffic": pmc_traffic(prof["kernel"], args, B, T),
+                "traffic": traffic,  # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes) or null
+                "traffic_algorithmic": 2.0 * B * (T * 64) * 128 * 2 if prof["kernel"].startswith("resblock_pair_g_bf16_k<GTile<128, 11") else None,
+                "mfma_util": util,
+                "counters_unavailable": why_not,
                 "kernel": prof["kernel"],
                 "launches": prof["launches"],
                 "avg_launch_ms": prof["ms"] / prof["launches"],
@@ -518,6 +545,9 @@ def main():
             res["pipeline_256"] = pipe
         if n_gpus == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        else:  # the key is always there: the CPU baseline is timed on rank 0 of the N = 1 run only (it would otherwise compete with the ranks' host threads)
+            res["cpu_baseline"] = None
+            res["cpu_baseline_skipped"] = "--no-cpu-baseline" if n_gpus == 1 else f"N = {n_gpus} > 1: the reference's CPU path is timed in the N = 1 run only"
         print(json.dumps(res), flush=True)
 
     barrier()

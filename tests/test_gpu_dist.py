@@ -1,0 +1,40 @@
+"""The N > 1 launch path on a ONE-GPU box: `bench.py --gpus 2` self-launches two ranks under torch.distributed.run (127.0.0.1), both on
+cuda:0 (VTTS_SHARE_GPU=1), collectives over gloo (VTTS_DIST_BACKEND=gloo) — the weight-blob broadcast, the barriers, the max-over-ranks
+timing and the two sharded legs (256-sentence pipeline, 10-minute utterance) all execute.  A development check of the multi-GPU code
+path (the reference has no counterpart: vietTTS/hifigan/mel2wave.py:20-41 is single-device), never a measurement."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parents[1]
+
+
+def test_two_ranks_share_one_gpu_and_shard_both_legs():
+    env = dict(os.environ, VTTS_DIST_BACKEND="gloo", VTTS_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--frames", "128",
+           "--no-cpu-baseline", "--no-f32"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["samples_per_step"] == 2 * 2 * 256 * 128  # both ranks' batches
+    assert "cpu_baseline" in d and d["cpu_baseline"] is None and "N = 2" in d["cpu_baseline_skipped"]
+    wb = d["weights_broadcast"]
+    assert wb["backend"] == "gloo" and wb["ranks_in_group"] == 2 and wb["bytes"] > 20e6  # ONE broadcast of the packed blob, then no collective on the data path
+    # sharded == unsharded, leg by leg: the same sentences / chunks were synthesised, each exactly once
+    import bench
+
+    one = bench.pipeline_256(256)
+    two = d["pipeline_256"]
+    assert "error" not in two, two
+    for k in ("sentences", "tokens", "frames", "samples"):
+        assert two[k] == one[k], (k, two[k], one[k])
+    lf = d["longform_10min"]
+    assert lf["chunks"] == -(-37500 // 512) and lf["first_chunk_ms"] > 0 and lf["total_ms"] >= lf["first_chunk_ms"]

@@ -96,7 +96,8 @@ int main(int argc, char** argv) {
     if (argc > 9) stagger = atoi(argv[9]);  // development builds with a start-offset switch (none in the tree now)
     if (argc > 8) dflags = atoi(argv[8]);  // timeline builds of kernels_bf16_rb.hip: experiment switches (results wrong)
     if (argc > 7) impl = atoi(argv[7]);  // kept for old command lines; there is one pair kernel (kernels_bf16_rbg.hip)
-    printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d\n", C, K, dil, B, L, impl, dflags, stagger);
+    const int acc_add = getenv("KB_ACC") ? atoi(getenv("KB_ACC")) : 0;  // 1: the chain's third launch (y = y + pair(x): MRF accumulate, model.py:118-120)
+    printf("pair C=%d K=%d dil=%d B=%d L=%d impl=%d dflags=%d stagger=%d acc_add=%d\n", C, K, dil, B, L, impl, dflags, stagger, acc_add);
     // impl 0: second generation (two workgroups per CU); impl 1: persistent software-pipelined kernel (kernels_bf16_rbp.hip)
 #ifdef KBENCH_NO_P
     auto launch = [&](const BConvArgs& aa) { return launch_pair_g_bf16(C, K, aa, 0); };
@@ -137,6 +138,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dw1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(dy, 0xff, n * 2));
+    std::vector<unsigned short> hy0;
+    if (acc_add) {  // the accumulator's previous content (last utterance only is checked; the others just need finite values)
+        hy0.resize(n);
+        for (size_t i = 0; i < n; ++i) hy0[i] = f2bf(0.7f * nd(rng));
+        CK(hipMemcpy(dy, hy0.data(), n * 2, hipMemcpyHostToDevice));
+    }
 
     BConvArgs a;
     memset(&a, 0, sizeof(a));
@@ -152,7 +159,7 @@ int main(int argc, char** argv) {
     a.pad = (K - 1) / 2 * dil;
     a.slope_in = 0.1f;
     a.slope_out = 1.0f;
-    a.acc_add = 0;
+    a.acc_add = acc_add;
     a.div = 1.0f;
     a.dbg = nullptr;
 
@@ -177,6 +184,11 @@ int main(int argc, char** argv) {
            flops / times[times.size() / 2] * 1e-9, flops / times[times.size() / 2] * 1e-9 / 2500.0);
 
     // ---- correctness on a window of the last utterance (start edge, an interior tile seam, end edge)
+    if (acc_add) {  // the timed launches accumulated reps + 1 times: one launch on the original accumulator content
+        CK(hipMemcpy(dy, hy0.data(), n * 2, hipMemcpyHostToDevice));
+        CK(launch(a));
+        CK(hipDeviceSynchronize());
+    }
     {
         const int nwin = 3, wlen = 700;
         const int t_los[nwin] = {0, L / 2 - 350, L - wlen};
@@ -197,6 +209,7 @@ int main(int argc, char** argv) {
             CK(hipMemcpy(yr.data(), dyref, yr.size() * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(yg.data(), dy + ((size_t)(B - 1) * L + t_lo) * C, yg.size() * 2, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < yr.size(); ++i) {
+                if (acc_add) yr[i] += bf2f(hy0[((size_t)(B - 1) * L + t_lo) * C + i]);
                 const double d = fabs((double)bf2f(yg[i]) - (double)yr[i]);
                 // allowed: bf16 rounding of the output (2^-9 rel) + accumulation-order noise
                 const double tol = fabs(yr[i]) * (1.0 / 256) + 2e-2;

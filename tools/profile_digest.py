@@ -1,0 +1,121 @@
+#!/usr/bin/env python
+"""Digest one tools/profile_final.sh run (kernel-trace .db + three --pmc CSV passes of the same bench command) into the files kept
+under profiles/:  <tag>_kernel_stats.md, <tag>_pmc.md, counters_bf16.json.     python tools/profile_digest.py <run dir> <tag>
+
+counters_bf16.json carries `source_digest` = viettts_amd.csrc.build._digest() of the tree that was profiled; bench.py reports its
+numbers only while that equals the digest of the sources of the library it loaded.
+
+  MfmaUtil          = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)   per launch, then averaged
+  HBM bytes         = FETCH_SIZE KiB x 1024 x 2 (gfx950: 16-byte-per-lane streams are tallied at half their bytes,
+                      MI355X_MICROARCH.md §HBM) + WRITE_SIZE KiB x 1024
+  time-weighted MfmaUtil over the ResBlock kernels = sum(util_k x time_k) / sum(time_k), time_k = calls x avg duration of the
+                      TIMED passes (the warm-up pass, the first third of each kernel's launches, is dropped)
+"""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def short(name):
+    return name.replace("void ", "").replace("vtts::", "")
+
+
+def main():
+    run, tag = sys.argv[1], sys.argv[2]
+    from viettts_amd.csrc.build import _digest
+
+    # ---- kernel trace: per-dispatch durations from the rocpd database --------------------------------------------------
+    dbs = glob.glob(os.path.join(run, "trace", "**", "*results.db"), recursive=True)
+    per = defaultdict(list)
+    if dbs:
+        db = sqlite3.connect(dbs[0])
+        try:
+            rows = db.execute("select name, start, end from kernels order by start").fetchall()
+        except sqlite3.Error:
+            rows = []
+        if not rows:  # older / newer schema: fall back to the view rocprofv3 --stats fills
+            for name, calls, tot, avg, _ in db.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+                per[short(name)] = [avg * 1e3] * calls
+        for name, st, en in rows:
+            per[short(name)].append(float(en - st))
+    stats = {}
+    for k, v in per.items():
+        n = len(v)
+        timed = v[n // 3:] if n >= 3 and n % 3 == 0 else v  # bench --warmup 1 --steps 2: the first third of a kernel's launches is the warm-up pass
+        stats[k] = {"calls": n, "avg_us_all": sum(v) / n / 1e3, "avg_us_timed": sum(timed) / len(timed) / 1e3, "timed_calls": len(timed)}
+    tot = sum(s["avg_us_timed"] * s["timed_calls"] for s in stats.values())
+    with open(os.path.join(run, f"{tag}_kernel_stats.md"), "w") as f:
+        f.write(f"# {tag} — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32` (bf16, B=64 x T=1024); "
+                f"source digest `{_digest()[:16]}`.  avg (timed) drops each kernel's warm-up-pass launches (first touch of the workspace).\n\n")
+        f.write("| kernel | calls | avg us (all) | avg us (timed passes) | % of timed GPU time |\n|---|---:|---:|---:|---:|\n")
+        for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us_timed"] * kv[1]["timed_calls"]):
+            pct = 100 * s["avg_us_timed"] * s["timed_calls"] / tot if tot else 0
+            if pct < 0.005:
+                continue
+            f.write(f"| `{k[:110]}` | {s['calls']} | {s['avg_us_all']:.1f} | {s['avg_us_timed']:.1f} | {pct:.2f} |\n")
+        f.write(f"| **all kernels, timed passes** | | | {tot:.0f} us total | 100 |\n")
+
+    # ---- counters ------------------------------------------------------------------------------------------------------
+    acc = defaultdict(lambda: defaultdict(list))
+    for fcsv in glob.glob(os.path.join(run, "pmc", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fcsv)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    kern = {}
+    for k, cs in acc.items():
+        g = lambda n: (sum(cs[n]) / len(cs[n])) if cs.get(n) else 0.0
+        util = g("SQ_VALU_MFMA_BUSY_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8 * 1024) if g("GRBM_GUI_ACTIVE") else None
+        # the stats table keys are untruncated kernel names; counters' too
+        st = stats.get(k)
+        fetch_b, write_b = g("FETCH_SIZE") * 1024 * 2, g("WRITE_SIZE") * 1024
+        kern[k] = {
+            "launches_counted": len(cs.get("SQ_VALU_MFMA_BUSY_CYCLES", cs.get("FETCH_SIZE", []))),
+            "mfma_util": util,
+            "wait_any_share": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAVE_CYCLES") else None,
+            "lds_bank_conflict_cycles": g("SQ_LDS_BANK_CONFLICT"),
+            "lds_idx_active_cycles": g("SQ_LDS_IDX_ACTIVE"),
+            "fetch_size_kib_raw": g("FETCH_SIZE"),
+            "hbm_read_bytes": fetch_b,
+            "hbm_write_bytes": write_b,
+            "l2_hit_rate": g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum")) if g("TCC_HIT_sum") + g("TCC_MISS_sum") else None,
+            "avg_us_timed": st["avg_us_timed"] if st else None,
+            "timed_calls": st["timed_calls"] if st else None,
+        }
+    rb = {k: v for k, v in kern.items() if k.startswith("resblock_") and v["mfma_util"] is not None and v["avg_us_timed"]}
+    tw = (sum(v["mfma_util"] * v["avg_us_timed"] * v["timed_calls"] for v in rb.values()) /
+          sum(v["avg_us_timed"] * v["timed_calls"] for v in rb.values())) if rb else None
+    with open(os.path.join(run, f"{tag}_pmc.md"), "w") as f:
+        f.write(f"# {tag} — PMC passes of the SAME bench command (one counter set per pass: SQ+GRBM | FETCH_SIZE | WRITE_SIZE+TCC hit/miss), source digest `{_digest()[:16]}`\n\n")
+        f.write("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); HBM GB = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch; "
+                "GB/s = HBM bytes / the kernel-trace pass's average duration (timed passes).\n\n")
+        f.write("| kernel | MfmaUtil | wait_any / wave_cycles | LDS bank-conflict cycles | read GB | write GB | L2 hit | avg us | HBM GB/s |\n|---|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+        for k, v in sorted(kern.items(), key=lambda kv: -(kv[1]["avg_us_timed"] or 0) * (kv[1]["timed_calls"] or 0)):
+            if v["mfma_util"] is None and not v["hbm_read_bytes"]:
+                continue
+            us = v["avg_us_timed"]
+            bw = (v["hbm_read_bytes"] + v["hbm_write_bytes"]) / (us * 1e-6) / 1e9 if us else None
+            fmt = lambda x, p: ("%." + str(p) + "f") % x if x is not None else ""
+            f.write(f"| `{k[:70]}` | {fmt(v['mfma_util'], 3)} | {fmt(v['wait_any_share'], 2)} | {v['lds_bank_conflict_cycles']:.3g} | {v['hbm_read_bytes'] / 1e9:.2f} | "
+                    f"{v['hbm_write_bytes'] / 1e9:.2f} | {fmt(v['l2_hit_rate'], 2)} | {fmt(us, 1)} | {fmt(bw, 0)} |\n")
+        if tw is not None:
+            f.write(f"\n**Time-weighted MfmaUtil over the ResBlock kernels ({len(rb)} kernel classes): {tw:.3f}**\n")
+    out = {
+        "source_digest": _digest(),
+        "tag": tag,
+        "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32  (bf16, B=64 x T=1024; kernel-trace pass + 3 --pmc passes, tools/profile_final.sh)",
+        "time_weighted_mfma_util_resblock_kernels": tw,
+        "kernels": kern,
+    }
+    with open(os.path.join(run, "counters_bf16.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"{tag}: {len(stats)} kernels traced, {len(kern)} with counters, time-weighted ResBlock MfmaUtil = {tw}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Counters for the build you bench.  On one MI355X box:
+#     gpurun --timeout 1500 -- 'bash tools/profile_final.sh r03_final'
+# runs, for THE SAME bench command (bf16, B = 64 x T = 1024):
+#   1. rocprofv3 --kernel-trace --stats                      -> per-kernel durations
+#   2. rocprofv3 --kernel-trace --pmc <SQ set + GRBM>        -> MfmaUtil, wait shares, LDS bank conflicts
+#   3. rocprofv3 --kernel-trace --pmc FETCH_SIZE             -> HBM bytes read   (own pass: TCC slots, MI355X_MICROARCH.md)
+#   4. rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# (counter passes never combined with sys/hip/hsa tracing) and digests them with tools/profile_digest.py into
+#   gpurun_out/<tag>/<tag>_kernel_stats.md, <tag>_pmc.md, counters_bf16.json
+# Copy those three into profiles/ (counters_bf16.json keeps its name): bench.py reports roofline.traffic / roofline.mfma_util from
+# counters_bf16.json only while its `source_digest` equals the digest of the sources the loaded library was built from.
+R=$PWD; T=${1:-r03_final}; O=$R/gpurun_out/$T; mkdir -p $O
+BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- $BENCH > $O/trace.log 2>&1
+i=0
+for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $O/pmc/p$i -- $BENCH > $O/pmc_p$i.log 2>&1
+done
+cd $R
+python tools/profile_digest.py $O $T
+find $O -name "*.csv" -size +5M -delete; find $O -name "*.db" -size +20M -delete

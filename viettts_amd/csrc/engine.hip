@@ -745,17 +745,24 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 // accumulator (bf16, rounded after every addition): those kernels are chained by events in the sequential order
                 // rb_0 -> rb_1 -> rb_2, so every sample sees the same additions and roundings as one-after-the-other — the same bits.
                 hipStream_t cs[4];
-                if ((rc = fork_streams(h, nk, s, cs))) return rc;
+                if ((rc = fork_streams(h, nk, s, cs))) {
+                    (void)join_streams(h, nk, s);
+                    return rc;
+                }
+                // every failure inside this block is collected in rc (no early return): the forked chain streams MUST be re-joined into
+                // `s` below, also when a launch fails — during graph capture an un-joined fork invalidates the capture
+                auto hip_rc = [&](hipError_t e, const char* what) -> int {
+                    return e == hipSuccess ? VTTS_OK : fail(VTTS_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+                };
                 for (int j = 0; j < nk && !rc; ++j) {
                     char* tT = wsb + (size_t)(2 + 2 * j) * per;
                     char* tC = wsb + (size_t)(3 + 2 * j) * per;
                     rc = run_chain(j, tT, tC, cs[j], [&]() -> int {
-                        if (j > 0) HIP_TRY(hipStreamWaitEvent(cs[j], h->ev_chain[j - 1], 0));
-                        return VTTS_OK;
+                        return j > 0 ? hip_rc(hipStreamWaitEvent(cs[j], h->ev_chain[j - 1], 0), "hipStreamWaitEvent(chain)") : VTTS_OK;
                     });
                     if (!rc && j + 1 < nk) {
-                        if (!h->ev_chain[j]) HIP_TRY(hipEventCreateWithFlags(&h->ev_chain[j], hipEventDisableTiming));
-                        HIP_TRY(hipEventRecord(h->ev_chain[j], cs[j]));
+                        if (!h->ev_chain[j]) rc = hip_rc(hipEventCreateWithFlags(&h->ev_chain[j], hipEventDisableTiming), "hipEventCreateWithFlags(chain)");
+                        if (!rc) rc = hip_rc(hipEventRecord(h->ev_chain[j], cs[j]), "hipEventRecord(chain)");
                     }
                 }
                 const int rj = join_streams(h, nk, s);
@@ -1424,6 +1431,12 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     }
     else if (!strcmp(name, "fuse")) *value = h->opt_fuse;
     else if (!strcmp(name, "hop")) *value = h->hop;
+    else if (!strcmp(name, "max_frames_per_pass")) {
+        // the smallest T check_pass_size() refuses (one utterance's largest activation must stay below 2^31 bytes; max_act_elems is linear
+        // in T): callers route longer utterances through the chunk scheduler — ONE rule, here
+        const size_t per = max_act_elems(h, 1) * (h->dtype == VTTS_BF16 ? 2 : sizeof(float));
+        *value = (int64_t)((((size_t)1 << 31) + per - 1) / per);
+    }
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;
     else if (!strcmp(name, "profile_K")) *value = h->prof_K;
     else return fail(VTTS_ERR_INVALID, "unknown option '%s'", name);

@@ -246,10 +246,10 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
             for (int nr = 0; nr < NR; ++nr) {
                 const int row = wn * (NT / WN) + nr * 32 + l31;
                 float4 v;
-                v.x = acc[mr][nr][4 * rq + 0] + bv.x;
-                v.y = acc[mr][nr][4 * rq + 1] + bv.y;
-                v.z = acc[mr][nr][4 * rq + 2] + bv.z;
-                v.w = acc[mr][nr][4 * rq + 3] + bv.w;
+                v.x = vadd_raw(acc[mr][nr][4 * rq + 0], bv.x);
+                v.y = vadd_raw(acc[mr][nr][4 * rq + 1], bv.y);
+                v.z = vadd_raw(acc[mr][nr][4 * rq + 2], bv.z);
+                v.w = vadd_raw(acc[mr][nr][4 * rq + 3], bv.w);
                 *reinterpret_cast<float4*>(ep + row * EPF + col) = v;
             }
         }
@@ -271,13 +271,13 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         const size_t g = ((size_t)b * Lp + t) * COUTP + mtile * MT + c8 * 8;
         if (res) {  // ResBlock residual  x = xt + x  (model.py:50)
             const uint4 r = *reinterpret_cast<const uint4*>(res + g);
-            v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-            v[4] += bf16_lo(r.z); v[5] += bf16_hi(r.z); v[6] += bf16_lo(r.w); v[7] += bf16_hi(r.w);
+            v[0] = vadd_raw(bf16_lo(r.x), v[0]); v[1] = vadd_raw(bf16_hi(r.x), v[1]); v[2] = vadd_raw(bf16_lo(r.y), v[2]); v[3] = vadd_raw(bf16_hi(r.y), v[3]);
+            v[4] = vadd_raw(bf16_lo(r.z), v[4]); v[5] = vadd_raw(bf16_hi(r.z), v[5]); v[6] = vadd_raw(bf16_lo(r.w), v[6]); v[7] = vadd_raw(bf16_hi(r.w), v[7]);
         }
         if (a.acc_add) {  // MRF  xs += rb(x)  (model.py:118-120)
             const uint4 o = *reinterpret_cast<const uint4*>(y + g);
-            v[0] = bf16_lo(o.x) + v[0]; v[1] = bf16_hi(o.x) + v[1]; v[2] = bf16_lo(o.y) + v[2]; v[3] = bf16_hi(o.y) + v[3];
-            v[4] = bf16_lo(o.z) + v[4]; v[5] = bf16_hi(o.z) + v[5]; v[6] = bf16_lo(o.w) + v[6]; v[7] = bf16_hi(o.w) + v[7];
+            v[0] = vadd_raw(bf16_lo(o.x), v[0]); v[1] = vadd_raw(bf16_hi(o.x), v[1]); v[2] = vadd_raw(bf16_lo(o.y), v[2]); v[3] = vadd_raw(bf16_hi(o.y), v[3]);
+            v[4] = vadd_raw(bf16_lo(o.z), v[4]); v[5] = vadd_raw(bf16_hi(o.z), v[5]); v[6] = vadd_raw(bf16_lo(o.w), v[6]); v[7] = vadd_raw(bf16_hi(o.w), v[7]);
         }
         if (a.div != 1.0f) {  // x = xs / num_kernels  (model.py:121)
 #pragma unroll
@@ -307,12 +307,8 @@ using BUp3 = BTile<64, 64, 64, 64, 3, 64, 256, 1, 4, 3, 1, false>;       // ups_
 
 template <class T>
 static hipError_t launch_b(const BConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;  // per device (vtts_internal.h)
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_bf16_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
     dim3 grid((a.L + T::NT - 1) / T::NT, T::COUTP / T::MT, a.B);
     hipLaunchKernelGGL(conv_bf16_k<T>, grid, dim3(T::THREADS), T::LDS_BYTES, s, a);
     return hipGetLastError();

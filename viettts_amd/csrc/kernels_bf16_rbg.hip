@@ -38,6 +38,13 @@
 #ifndef VTTS_XCD_MAP  // XCD-aware tile order (A/B switch, tools/kbench): see resblock_pair_g_bf16_k
 #define VTTS_XCD_MAP 1
 #endif
+#ifndef VTTS_RES_MFMA  // residual / MRF rows added by the matrix cores (identity A fragments) instead of unpack + v_add: A/B switch, tools/kbench.
+#define VTTS_RES_MFMA 0  // Correct and bit-stable, but NOT faster (round 3, profiles/r03_a_coissue_findings.md): -290 VALU per tile buy nothing
+#endif                   // because the requests that feed it are VMEM, which an MFMA stream on the same SIMD blocks just as it blocks the adds' loads
+
+#ifndef VTTS_PACE_NOP  // kernel-development switch (tools/kbench): s_nop <n> after every MFMA of the main loops (-1 = none)
+#define VTTS_PACE_NOP -1
+#endif
 #ifndef VTTS_LEAN  // lean loop addressing (buffer loads with SGPR offsets, per-tap swizzle terms): A/B switch, tools/kbench
 #define VTTS_LEAN 1
 #endif
@@ -71,11 +78,11 @@ struct GTile {
     static_assert(C % XC == 0 && (NXC == 1 || !UNROLL_ALL), "channel chunking");
     static_assert(SPR1 == 4 || SPR1 == 8 || SPR1 == 16, "X row pitch 64..256 B");
     static_assert(SPR2 == 4 || SPR2 == 8 || SPR2 == 16 || SPR2 == 32, "xt row pitch 64..512 B");
-    static int lds_bytes(int dil) {
-        const int bx = (N1 + 2 * H2 * dil) * P1, bt = ROWST * P2;
+    static int lds_bytes(int dil) {  // rows in multiples of 16 (tile_off's blocks of 16 rows at C = 32 / 64)
+        const int bx = tile_rows16(N1 + 2 * H2 * dil) * P1, bt = tile_rows16(ROWST) * P2;
         return bx > bt ? bx : bt;
     }
-    static_assert(ROWSX_MAX * P1 <= 160 * 1024 && ROWST * P2 <= 160 * 1024, "LDS budget");
+    static_assert(tile_rows16(ROWSX_MAX) * P1 <= 160 * 1024 && tile_rows16(ROWST) * P2 <= 160 * 1024, "LDS budget");
 };
 
 template <class T>
@@ -152,11 +159,14 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         constexpr int XB = decltype(xb_tag)::value;
         constexpr int RPI = THREADS / SPR1;  // tile rows between a thread's consecutive 16-byte units
         static_assert(THREADS % SPR1 == 0 && RPI % 16 == 0, "a thread's units share their column and their swizzle");
-        const int nunits = rowsx * SPR1;
         const int tx0 = t0 - H2 - h1;
-        const int row0 = tid / SPR1, c = tid % SPR1;
+        // a wave loads 64 / SPR1 whole rows (1 KiB contiguous).  Row-major tiles (SPR1 >= 16): lane -> (row, slot) in memory order.
+        // Blocked tiles (SPR1 = 4, 8): 8 consecutive lanes take 8 consecutive rows of one slot, which is what keeps the
+        // ds_write_b128 conflict-free there (tile_off); the wave touches the same cache lines either way.
+        constexpr int RW = 64 / SPR1;  // rows per wave and unit
+        const int row0 = (SPR1 >= 16 || !VTTS_TILE_BLOCKED) ? tid / SPR1 : wave * RW + lane % RW, c = (SPR1 >= 16 || !VTTS_TILE_BLOCKED) ? tid % SPR1 : lane / RW;
         auto act2 = [](unsigned u) { return lrelu01_pack(bf16_lo(u), bf16_hi(u)); };  // LRELU_SLOPE, model.py:5,46
-        unsigned char* const lds0 = xt + row0 * P1 + ((c ^ swz_of<SPR1>(row0)) << 4);  // unit i: + i * RPI * P1 (same swizzle)
+        unsigned char* const lds0 = xt + tile_off<SPR1>(row0, c);  // unit i: + i * RPI * P1 (RPI is a multiple of 16: same swizzle / same place in its block)
         if (tx0 >= 0 && tx0 + XPT * RPI <= L) {
             // interior tile (all but the first / last of an utterance): no clamping, no masking, constant strides
             const unsigned short* __restrict__ g0 = xg + (size_t)(tx0 + row0) * C + xc * XC + c * 8;
@@ -194,9 +204,8 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             // hipcc wait for each one before issuing the next
 #pragma unroll
             for (int i = 0; i < XB; ++i) {
-                const int u = tid + (i0 + i) * THREADS;
                 const int t = tx0 + row0 + (i0 + i) * RPI;
-                okx[i] = i0 + i < XPT && u < nunits && t >= 0 && t < L;
+                okx[i] = i0 + i < XPT && row0 + (i0 + i) * RPI < rowsx && t >= 0 && t < L;
                 const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
                 v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * C + xc * XC + c * 8);
             }
@@ -239,15 +248,17 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int row = rowbase0 + tap * dl + nr * 32;
-                bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + row * PB + (((ks * 2 + lh) ^ swz_of<SPRB>(row)) << 4));
+                bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + tile_off<SPRB>(row, ks * 2 + lh));
             }
         };
         auto mfma_step = [&](int slot, int par, bool first) {
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr)
+                for (int nr = 0; nr < NR; ++nr) {
                     acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[slot][mr], bf[par][nr], first ? bblk[mr] : acc[mr][nr], 0, 0, 0);
+
+                }
         };
         // keep hipcc's scheduler from sinking the look-ahead loads to their uses (it does, to save registers), and spread
         // them between the MFMAs: grouped issue (all loads, then all MFMAs) left the matrix pipe idle while a lone wave
@@ -305,11 +316,16 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             };
             auto tap_terms = [&](int tap, unsigned& tapaddr, unsigned& xs) {
                 const int row = rowbase0 + tap * dl;
-                tapaddr = (unsigned)row * PB;
-                xs = (unsigned)(swz_of<SPRB>(row) ^ lh) << 4;
+                if constexpr (SPRB >= 16 || !VTTS_TILE_BLOCKED) {
+                    tapaddr = (unsigned)row * PB;
+                    xs = (unsigned)(swz_of<SPRB>(row) ^ lh) << 4;
+                } else {  // blocked tile: slot 2*ks + lh is 512*ks + 256*lh bytes into the row's block
+                    tapaddr = (unsigned)tile_off<SPRB>(row, lh);
+                    xs = 0;
+                }
             };
             auto load_b2 = [&](unsigned tapaddr, unsigned xs, int ks, int par) {
-                const unsigned addr = tapaddr + (xs ^ (unsigned)(ks << 5));
+                const unsigned addr = (SPRB >= 16 || !VTTS_TILE_BLOCKED) ? tapaddr + (xs ^ (unsigned)(ks << 5)) : tapaddr + (unsigned)(ks << 9);
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + addr + nr * 32 * PB);
             };
@@ -321,6 +337,33 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 const int tapn = tap + 1 < KS ? tap + 1 : KS - 1;
                 tap_terms(wrap ? tapn : tap, tn, xn);
                 const int ksn = wrap ? 0 : ksb + UB;
+#if VTTS_PACE_NOP >= 0
+                // kernel-development variant (tools/kbench): every MFMA followed by s_nop <n> and ONE look-ahead load, order pinned by
+                // sched_barrier — does a paced MFMA stream leave the co-resident workgroup's VALU phases more issue slots?
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const int sa = s0 + i + PA, sc = sa < NSTEPS ? sa : NSTEPS - 1;
+                    const int tapa = sc / NKS, ksa = sc - tapa * NKS;
+                    const int soff = ((tapa * KSTEPS + ks0 + ksa) * MB) * 1024;
+                    static_assert(SPRB >= 16, "the paced experiment addresses row-major tiles only");
+                    const unsigned baddr = (i + 1 < UB) ? ta + (xs ^ (unsigned)((ksb + i + 1) << 5)) : tn + (xn ^ (unsigned)(ksn << 5));
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MR * NR; ++m) {
+                        const int mr = m / NR, nr = m % NR;
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % RA][mr], bf[i & 1][nr],
+                                                                              (decltype(first_tag)::value && i == 0) ? bblk[mr] : acc[mr][nr], 0, 0, 0);
+                        asm volatile("s_nop %0" ::"n"(VTTS_PACE_NOP));
+                        if (m < MR) {
+                            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + m * 1024, soff, 0);
+                            af[(i + PA) % RA][m] = __builtin_bit_cast(bf16x8, v);
+                        } else if (m - MR < NR) {
+                            bf[(i + 1) & 1][m - MR] = *reinterpret_cast<const bf16x8*>(xt + baddr + (m - MR) * 32 * PB);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < UB; ++i) {
                     load_a2(s0 + i + PA, (i + PA) % RA);
@@ -329,6 +372,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     mfma_step(i % RA, i & 1, decltype(first_tag)::value && i == 0);
                     pin_step(true);
                 }
+#endif
             };
 #else
             auto block = [&](int s0, auto first_tag) {  // the first block of a fresh pass is peeled: its first step reads the bias block
@@ -373,8 +417,36 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         qd = r[1];
     };
 
+#if VTTS_RES_MFMA
+    // The residual `x = xt + x` (model.py:50) and the MRF accumulate `xs += rb(x)` (model.py:118-120) on the matrix cores: rows of a
+    // [B][L][C] tensor, loaded 16 bytes per lane as (time l31, channels 16p + 8lh ..) of this wave's m-block, ARE the B fragment of
+    // a k-step whose A fragment is the identity block (row m <-> channel 16p + k), so  acc += I_p * rows  is one MFMA per 8 values
+    // where the vector path needs 2 v_permlane32_swap + 8 unpacks + 8 v_add on the issue port the co-resident workgroup's MFMAs
+    // need (profiles/r01_j_kbench_findings.md: ~290 of a tile's ~1400 VALU instructions per wave, twice that on a chain's third
+    // launch).  Products by 1.0 and sums with 15 zeros are exact: the value is the fp32 sum acc + x, rounded once, as before.
+    // The residual rows are requested one per unit of epilogue 1 (whose accumulator registers die unit by unit), land under
+    // it, and open phase 2:  acc2 = (b2 + x) + c2(xt)  instead of  (b2 + c2(xt)) + x.
+    uint4 rv[MR][2][NR];
+    auto res_row = [&](const unsigned short* __restrict__ src, int mr, int p, int nr) {
+        const int t = t0 + wn * (N1 / WN) + nr * 32 + l31;
+        const int tc = t < L ? t : L - 1;  // rows past the end are never stored: any in-bounds address will do
+        return *reinterpret_cast<const uint4*>(src + (size_t)tc * C + wm * (C / T::WM) + mr * 32 + 16 * p + 8 * lh);
+    };
+    auto ident_frag = [&](int p) {  // A fragment of I_p: lane (m = l31, k-group lh) holds k = 8lh .. 8lh+7; 1.0 where m == 16p + k
+        const int j = l31 - 16 * p - 8 * lh;
+        uint4 f;
+        f.x = j == 0 ? 0x3f80u : (j == 1 ? 0x3f800000u : 0u);
+        f.y = j == 2 ? 0x3f80u : (j == 3 ? 0x3f800000u : 0u);
+        f.z = j == 4 ? 0x3f80u : (j == 5 ? 0x3f800000u : 0u);
+        f.w = j == 6 ? 0x3f80u : (j == 7 ? 0x3f800000u : 0u);
+        return __builtin_bit_cast(bf16x8, f);
+    };
+#endif
+
     // ---------------- epilogue 1: LeakyReLU(0.1), bf16, zero outside [0, L) -> xt tile in LDS ----------------
+#if !VTTS_RES_MFMA
     load_bias(a.bias + C);  // c2's bias: lands while epilogue 1 runs
+#endif
     {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -395,21 +467,41 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     swap_pair(p0, q0);
                     swap_pair(p1, q1);
                     const int slot = (cb >> 3) + lh;
-                    *reinterpret_cast<uint4*>(xt + row * P2 + ((slot ^ swz_of<SPR2>(row)) << 4)) = make_uint4(p0, p1, q0, q1);
+                    *reinterpret_cast<uint4*>(xt + tile_off<SPR2>(row, slot)) = make_uint4(p0, p1, q0, q1);
+#if VTTS_RES_MFMA
+                    rv[mr][p][nr] = res_row(xg, mr, p, nr);  // into the registers this unit's accumulators just left
+#endif
                 }
             }
         }
+#if VTTS_RES_MFMA
+        load_bias(a.bias + C);  // c2's bias, once epilogue 1's accumulators are dead (the residual rows took their registers): lands under the barrier
+#endif
         // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
         for (int u = tid; u < 2 * H2 * SPR2; u += THREADS) {
             const int row = N1 + u / SPR2, c = u % SPR2;
-            *reinterpret_cast<uint4*>(xt + row * P2 + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(xt + tile_off<SPR2>(row, c)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     __syncthreads();  // B3: xt tile written
     VTTS_TL(a, wg_lin, 3);
 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
+#if VTTS_RES_MFMA
+    {
+        const bf16x8 id0 = ident_frag(0), id1 = ident_frag(1);
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id0, __builtin_bit_cast(bf16x8, rv[mr][0][nr]), bblk[mr], 0, 0, 0);
+                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id1, __builtin_bit_cast(bf16x8, rv[mr][1][nr]), acc[mr][nr], 0, 0, 0);
+            }
+    }
+    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::false_type{});
+#else
     conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::true_type{});
+#endif
     VTTS_TL(a, wg_lin, 4);
 
     // ---------------- epilogue 2: + x [MRF accumulate / mean] [consumer's LeakyReLU] -> bf16, 16-byte stores ----------------
@@ -445,14 +537,33 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                         swap_pair(r.x, r.z);  // un-swap the chunk into the accumulator layout
                         swap_pair(r.y, r.w);
                         const int r0 = 8 * p;
-                        acc[mr][nr][r0 + 0] = bf16_lo(r.x) + acc[mr][nr][r0 + 0]; acc[mr][nr][r0 + 1] = bf16_hi(r.x) + acc[mr][nr][r0 + 1];
-                        acc[mr][nr][r0 + 2] = bf16_lo(r.y) + acc[mr][nr][r0 + 2]; acc[mr][nr][r0 + 3] = bf16_hi(r.y) + acc[mr][nr][r0 + 3];
-                        acc[mr][nr][r0 + 4] = bf16_lo(r.z) + acc[mr][nr][r0 + 4]; acc[mr][nr][r0 + 5] = bf16_hi(r.z) + acc[mr][nr][r0 + 5];
-                        acc[mr][nr][r0 + 6] = bf16_lo(r.w) + acc[mr][nr][r0 + 6]; acc[mr][nr][r0 + 7] = bf16_hi(r.w) + acc[mr][nr][r0 + 7];
+                        acc[mr][nr][r0 + 0] = vadd_raw(bf16_lo(r.x), acc[mr][nr][r0 + 0]); acc[mr][nr][r0 + 1] = vadd_raw(bf16_hi(r.x), acc[mr][nr][r0 + 1]);
+                        acc[mr][nr][r0 + 2] = vadd_raw(bf16_lo(r.y), acc[mr][nr][r0 + 2]); acc[mr][nr][r0 + 3] = vadd_raw(bf16_hi(r.y), acc[mr][nr][r0 + 3]);
+                        acc[mr][nr][r0 + 4] = vadd_raw(bf16_lo(r.z), acc[mr][nr][r0 + 4]); acc[mr][nr][r0 + 5] = vadd_raw(bf16_hi(r.z), acc[mr][nr][r0 + 5]);
+                        acc[mr][nr][r0 + 6] = vadd_raw(bf16_lo(r.w), acc[mr][nr][r0 + 6]); acc[mr][nr][r0 + 7] = vadd_raw(bf16_hi(r.w), acc[mr][nr][r0 + 7]);
                     }
         };
+#if VTTS_RES_MFMA
+        if (a.acc_add != 0) {                                               // xs += rb(x)       (model.py:118-120)
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) rv[mr][p][nr] = res_row(yg, mr, p, nr);
+            const bf16x8 id0 = ident_frag(0), id1 = ident_frag(1);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) {
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id0, __builtin_bit_cast(bf16x8, rv[mr][0][nr]), acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id1, __builtin_bit_cast(bf16x8, rv[mr][1][nr]), acc[mr][nr], 0, 0, 0);
+                }
+        }
+#else
         add_rows(xg);                                                       // x = xt + x        (model.py:50)
         if (a.acc_add != 0) add_rows(yg);                                   // xs += rb(x)       (model.py:118-120)
+#endif
         VTTS_TL(a, wg_lin, 12);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -521,13 +632,8 @@ template <int KS> using G32S = GTile<32, KS, 256, 1, 4, 3, 2>;
 constexpr long G_MIN_WGS = 384;  // below this many wide-tile workgroups (1.5 per CU slot pair) the narrow tile is launched
 template <class T>
 static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_pair_g_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           T::lds_bytes(T::MAXDIL) + VTTS_EXP_LDS_PAD);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;  // per device (vtts_internal.h)
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_g_bf16_k<T>), T::lds_bytes(T::MAXDIL) + VTTS_EXP_LDS_PAD, once); e != hipSuccess) return e;
     if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
     dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
 #if VTTS_XCD_MAP

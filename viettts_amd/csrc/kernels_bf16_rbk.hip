@@ -45,7 +45,7 @@ struct RBTile {
     static constexpr int NQT = KS * KSTEPS;             // k-steps per convolution
     static constexpr int MB = C / 32;
     static constexpr int RA = PA + 1;
-    static constexpr int TILE_BYTES = ROWS * P;
+    static constexpr int TILE_BYTES = tile_rows16(ROWS) * P;  // rows in multiples of 16 (tile_off's blocks at C = 32 / 64)
     static constexpr int BIAS_BYTES = 6 * C * 4;        // the six convolutions' biases, staged once
     static constexpr int LDS_BYTES = 2 * TILE_BYTES + BIAS_BYTES;
     static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;
@@ -103,14 +103,16 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         const int tile = u / (2 * GUARD * SPR), v = u % (2 * GUARD * SPR);
         const int gr = v / SPR, c = v % SPR;
         const int row = gr < GUARD ? gr : W + gr;  // [0, GUARD) and [GUARD + W, ROWS)
-        *reinterpret_cast<uint4*>((tile ? tT : tA) + row * P + (c << 4)) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>((tile ? tT : tA) + tile_off<SPR>(row, c)) = make_uint4(0u, 0u, 0u, 0u);
     }
     // ---- stage A = lrelu(x) over the window (zero outside the utterance) ----
     {
         constexpr int RPI = THREADS / SPR;  // window rows between a thread's consecutive 16-byte units
         static_assert(THREADS % SPR == 0 && RPI % 16 == 0 && (W * SPR) % THREADS == 0, "a thread's units share their column and their swizzle");
-        const int r0 = tid / SPR, c = tid % SPR;
-        unsigned char* const lds0 = tA + (GUARD + r0) * P + ((c ^ swz_of<SPR>(GUARD + r0)) << 4);  // unit i: + i * RPI * P
+        // lane -> (row, slot) as in resblock_pair_g_bf16_k: blocked tiles (SPR = 4, 8) give 8 consecutive lanes 8 consecutive rows of one slot
+        constexpr int RW = 64 / SPR;
+        const int r0 = (SPR >= 16 || !VTTS_TILE_BLOCKED) ? tid / SPR : wave * RW + lane % RW, c = (SPR >= 16 || !VTTS_TILE_BLOCKED) ? tid % SPR : lane / RW;
+        unsigned char* const lds0 = tA + tile_off<SPR>(GUARD + r0, c);  // unit i: + i * RPI * P (RPI is a multiple of 16)
         uint4 v[XPT];
         if (tw >= 0 && tw + W <= L) {  // interior window: no clamping, no masking, constant strides
             const unsigned short* __restrict__ g0 = xg + (size_t)(tw + r0) * C + c * 8;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int row = GUARD + col0 + nr * 32 + (tap - H) * dl;
-                bf[par][nr] = *reinterpret_cast<const bf16x8*>(tile + row * P + (((ks * 2 + lh) ^ swz_of<SPR>(row)) << 4));
+                bf[par][nr] = *reinterpret_cast<const bf16x8*>(tile + tile_off<SPR>(row, ks * 2 + lh));
             }
         };
         auto step = [&](int q, int i, bool has_b) {  // i = q mod 4: ring slot and B parity are compile-time
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         swap_pair(p0, q0);
         swap_pair(p1, q1);
         const int slot = ((cb0 + 32 * mr) >> 3) + 2 * p + lh;
-        *reinterpret_cast<uint4*>(tile + row * P + ((slot ^ swz_of<SPR>(row)) << 4)) = make_uint4(p0, p1, q0, q1);
+        *reinterpret_cast<uint4*>(tile + tile_off<SPR>(row, slot)) = make_uint4(p0, p1, q0, q1);
     };
 
     __syncthreads();  // tile A staged, biases in LDS
@@ -282,10 +284,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     const int r0 = 8 * p;
                     const uint4 r = xr[mr][nr][p];
                     f32x16& c = acc[mr][nr];
-                    c[r0 + 0] += bf16_lo(r.x); c[r0 + 1] += bf16_hi(r.x);
-                    c[r0 + 2] += bf16_lo(r.y); c[r0 + 3] += bf16_hi(r.y);
-                    c[r0 + 4] += bf16_lo(r.z); c[r0 + 5] += bf16_hi(r.z);
-                    c[r0 + 6] += bf16_lo(r.w); c[r0 + 7] += bf16_hi(r.w);
+                    c[r0 + 0] = vadd_raw(bf16_lo(r.x), c[r0 + 0]); c[r0 + 1] = vadd_raw(bf16_hi(r.x), c[r0 + 1]);
+                    c[r0 + 2] = vadd_raw(bf16_lo(r.y), c[r0 + 2]); c[r0 + 3] = vadd_raw(bf16_hi(r.y), c[r0 + 3]);
+                    c[r0 + 4] = vadd_raw(bf16_lo(r.z), c[r0 + 4]); c[r0 + 5] = vadd_raw(bf16_hi(r.z), c[r0 + 5]);
+                    c[r0 + 6] = vadd_raw(bf16_lo(r.w), c[r0 + 6]); c[r0 + 7] = vadd_raw(bf16_hi(r.w), c[r0 + 7]);
                 }
         if (pr < 2) {
             // the pair-by-pair path stores x' as bf16 and the next pair reloads it: round here the same way, keep it as
@@ -346,8 +348,8 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                         uint4 o = xr[mr][nr][p];
                         swap_pair(o.x, o.z);
                         swap_pair(o.y, o.w);
-                        v[0] = bf16_lo(o.x) + v[0]; v[1] = bf16_hi(o.x) + v[1]; v[2] = bf16_lo(o.y) + v[2]; v[3] = bf16_hi(o.y) + v[3];
-                        v[4] = bf16_lo(o.z) + v[4]; v[5] = bf16_hi(o.z) + v[5]; v[6] = bf16_lo(o.w) + v[6]; v[7] = bf16_hi(o.w) + v[7];
+                        v[0] = vadd_raw(bf16_lo(o.x), v[0]); v[1] = vadd_raw(bf16_hi(o.x), v[1]); v[2] = vadd_raw(bf16_lo(o.y), v[2]); v[3] = vadd_raw(bf16_hi(o.y), v[3]);
+                        v[4] = vadd_raw(bf16_lo(o.z), v[4]); v[5] = vadd_raw(bf16_hi(o.z), v[5]); v[6] = vadd_raw(bf16_lo(o.w), v[6]); v[7] = vadd_raw(bf16_hi(o.w), v[7]);
                     }
                     if (dv != 1.0f) {  // x = xs / num_kernels  (model.py:121)
 #pragma unroll
@@ -373,12 +375,8 @@ template <int KS> using RB128 = RBTile<128, KS, 128, 2, 2, 3, 2>;
 
 template <class T>
 static hipError_t launch_rb(const BConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;  // per device (vtts_internal.h)
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&resblock_bf16_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
     int dsum = 0;
     for (int i = 0; i < 3; ++i) {
         if (a.dils[i] < 1 || a.dils[i] > T::MAXDIL) return hipErrorInvalidValue;

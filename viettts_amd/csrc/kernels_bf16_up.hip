@@ -243,12 +243,8 @@ using UT3 = UTile<64, 64, 512, 1, 4, 1, 3, 2>;     // ups_3: 64 -> 2 x 32, k = 4
 
 template <class T>
 static hipError_t launch_u(const BConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&convt_g_bf16_k<T>), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;  // per device (vtts_internal.h)
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&convt_g_bf16_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
     const long tiles = (long)((a.L + T::N1 - 1) / T::N1) * a.B;
     int gy = 1;
     while (gy < T::NCH && tiles * gy < 512) gy *= 2;  // NCH is a power of two

@@ -205,13 +205,8 @@ template <int KS> using Tile32S = ConvTile<32, 32, KS, 32, 128, 1, 4, 32, false>
 
 template <class T>
 static hipError_t launch_tile(const ConvArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_f32_mfma_k<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static DynLdsOnce once;  // per device (vtts_internal.h)
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv1d_f32_mfma_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
     dim3 grid((a.L + T::NT - 1) / T::NT, T::COUT / T::MT, a.B);
     hipLaunchKernelGGL(conv1d_f32_mfma_k<T>, grid, dim3(256), T::LDS_BYTES, s, a);
     return hipGetLastError();

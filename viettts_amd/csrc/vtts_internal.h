@@ -10,6 +10,23 @@ namespace vtts {
 // engine.hip: record the calling thread's last error message (vtts_last_error()) and return `code`
 int set_error(int code, const char* msg);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the function ON A DEVICE: a process that drives several GPUs (a
+// second Generator on cuda:1 after cuda:0) must set it once per device, not once per process.  `done` = the caller's static
+// per-kernel table; devices beyond it just set the attribute on every launch (cheap next to a launch).
+struct DynLdsOnce {
+    bool done[32] = {};
+};
+inline hipError_t set_max_dynamic_lds(const void* fn, int bytes, DynLdsOnce& once) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool tracked = dev >= 0 && dev < 32;
+    if (tracked && once.done[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && tracked) once.done[dev] = true;
+    return e;
+}
+
 // How a convolution's result is combined with what is already in memory.  This is where
 // ResBlock1's residual (model.py:50 `x = xt + x`) and the MRF mean (model.py:115-121
 // `xs = rb0; xs += rb1; xs += rb2; x = xs / 3`) are fused into the producing kernel.

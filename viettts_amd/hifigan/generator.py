@@ -67,12 +67,7 @@ class Generator:
     def max_frames_per_pass(self) -> int:
         """Utterances of this many mel frames or more are refused by the C ABI (an utterance's largest activation must stay
         below 2^31 bytes: include/vtts_hifigan.h, vtts_hifigan_workspace_bytes); they go through viettts_amd.longform."""
-        c, L, best = self.cfg.upsample_initial_channel, 1, self.cfg.upsample_initial_channel
-        for i, r in enumerate(self.cfg.upsample_rates):
-            L *= r
-            best = max(best, (c >> (i + 1)) * L)
-        es = 2 if self.dtype_name == "bf16" else 4
-        return -(-(1 << 31) // (best * es))
+        return self.get_option("max_frames_per_pass")  # the engine's own rule (engine.hip: check_pass_size), not a copy of it
 
     @property
     def packed_bytes(self) -> int:
