@@ -291,6 +291,7 @@ def main():
     ap.add_argument("--microbatch", type=int, default=0)
     ap.add_argument("--streams", type=int, default=0, help="micro-batches in flight on separate HIP streams (0 = engine default)")
     ap.add_argument("--chains", type=int, default=-1, help="engine option 'chains' (0 / 1 / 2; -1 = engine default)")
+    ap.add_argument("--fuse", type=int, default=-1, help="engine option 'fuse' (0..3; -1 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
@@ -325,6 +326,8 @@ def main():
         gen.set_option("streams", args.streams)
     if args.chains >= 0:
         gen.set_option("chains", args.chains)
+    if args.fuse >= 0:
+        gen.set_option("fuse", args.fuse)
     bstats = {}
     vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info, bstats)
 

@@ -238,6 +238,64 @@ __global__ __launch_bounds__(512) void coissue_k(Rec* out, float* sink, int mode
     }
 }
 
+// intra-wave overlap: every MFMA followed by FILL plain VALU instructions (the epilogue's kinds: v_mul, v_max, v_cvt_pk on 4 independent
+// chains) and optionally one ds_read_b128 — what a software-pipelined loop (the other column half's epilogue under this half's MFMAs) issues
+template <int FILL, int DSR>
+__global__ __launch_bounds__(512) void filler_k(Rec* out, float* sink, int both, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int wave = threadIdx.x >> 6;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = (__bf16)(0.001f * (threadIdx.x & 31));
+        b[e] = (__bf16)(0.002f * (threadIdx.x & 15));
+    }
+    float v[8];
+    unsigned u[4] = {1u, 2u, 3u, 4u};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.25f * j + threadIdx.x;
+    const float ks = 0.1f;
+    const unsigned addr = (threadIdx.x & 255) * 16;
+    u32x4 q;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    if (wave < 4 || both) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+                if (DSR) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q) : "v"(addr), "n"(j * 4096));
+#pragma unroll
+                for (int f = 0; f < FILL; ++f) {
+                    const int c = (j * FILL + f) & 3;
+                    if ((f % 3) == 0) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(v[c]) : "v"(v[c + 4]), "v"(ks));
+                    if ((f % 3) == 1) asm volatile("v_max_f32 %0, %1, %2" : "=v"(v[c + 4]) : "v"(v[c]), "v"(v[c + 4]));
+                    if ((f % 3) == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[c]) : "v"(v[c]), "v"(v[c + 4]));
+                }
+            }
+            if (DSR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float sres = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + v[0] + __builtin_bit_cast(float, u[0]) + (DSR ? __builtin_bit_cast(float, q[0]) : 0.f);
+    if (sres == 123.456f) *sink = sres;
+    if ((threadIdx.x & 63) == 0) {
+        Rec r;
+        r.t0 = t0;
+        r.t1 = t1;
+        r.hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        r.role = wave < 4 ? 0 : 1;
+        out[blockIdx.x * 8 + wave] = r;
+    }
+}
+typedef void (*fill_t)(Rec*, float*, int, int);
+
 typedef void (*kern_t)(Rec*, float*, int, int, int, int, int, const float*);
 struct Variant {
     const char* name;
@@ -291,6 +349,29 @@ int main(int argc, char** argv) {
     for (auto& v : vs) {
         run(v, 0, 0, 0, iters_a, 0, ca, cb, ss);
         printf("  A alone, %-12s : %.3f ticks / MFMA (x%.3f)\n", v.name, ca / (iters_a * 8.0), ca / (iters_a * 8.0) / a_alone);
+    }
+    if (argc > 2 && atoi(argv[2]) == 2) {  // intra-wave fillers
+        struct FV { const char* name; fill_t k; };
+        const FV fv[] = {{"0", filler_k<0, 0>}, {"2", filler_k<2, 0>}, {"4", filler_k<4, 0>}, {"6", filler_k<6, 0>}, {"8", filler_k<8, 0>}, {"12", filler_k<12, 0>},
+                         {"0+ds_read", filler_k<0, 1>}, {"4+ds_read", filler_k<4, 1>}, {"6+ds_read", filler_k<6, 1>}, {"8+ds_read", filler_k<8, 1>}};
+        printf("cycles per MFMA of a wave whose every MFMA is followed by F plain VALU instructions (v_mul / v_max / v_cvt_pk, 4 chains) [+ one ds_read_b128]:\n");
+        for (auto& f : fv) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(f.k), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+            double r[2];
+            for (int both = 0; both < 2; ++both) {
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipLaunchKernelGGL(f.k, dim3(nwg), dim3(512), 100 * 1024, 0, d, sink, both, 800);
+                    CK(hipDeviceSynchronize());
+                }
+                CK(hipMemcpy(h.data(), d, h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+                double sa = 0;
+                for (int w = 0; w < nwg; ++w)
+                    for (int i = 0; i < (both ? 8 : 4); ++i) sa += (double)(h[w * 8 + i].t1 - h[w * 8 + i].t0);
+                r[both] = sa / (nwg * (both ? 8 : 4)) / (800 * 4.0);
+            }
+            printf("  F = %-10s one wave per SIMD: %6.2f cycles / MFMA    two waves per SIMD (both the same stream): %6.2f cycles / MFMA per wave = %6.2f per SIMD\n", f.name, r[0], r[1], r[1] / 2);
+        }
+        return 0;
     }
     if (fine) {
         const int vsel[] = {0, 2, 5, 6};  // A unpaced, s_nop 1, s_nop 7, s_nop 11

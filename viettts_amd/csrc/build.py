@@ -72,6 +72,8 @@ def _build(force, verbose, stamp, out, libname) -> Path:
     def compile_one(src: str) -> Path:
         obj = OBJDIR / (Path(src).stem + "." + libname + ".o")
         per_file = [] if os.environ.get("VTTS_BUILD_NO_FILE_FLAGS") else FILE_FLAGS.get(src, [])  # experiment builds only (A/B of the flag itself)
+        if src in os.environ.get("VTTS_BUILD_NOSLP_FILES", "").split(","):
+            per_file = ["-fno-slp-vectorize"]
         cmd = [hipcc, *FLAGS, *per_file, "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)

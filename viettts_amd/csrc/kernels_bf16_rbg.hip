@@ -42,6 +42,9 @@
 #define VTTS_RES_MFMA 0  // Correct and bit-stable, but NOT faster (round 3, profiles/r03_a_coissue_findings.md): -290 VALU per tile buy nothing
 #endif                   // because the requests that feed it are VMEM, which an MFMA stream on the same SIMD blocks just as it blocks the adds' loads
 
+#ifndef VTTS_WREG  // C = 32: the convolution's weights register-resident for the whole phase (A/B switch, tools/kbench)
+#define VTTS_WREG 1
+#endif
 #ifndef VTTS_PACE_NOP  // kernel-development switch (tools/kbench): s_nop <n> after every MFMA of the main loops (-1 = none)
 #define VTTS_PACE_NOP -1
 #endif
@@ -72,6 +75,9 @@ struct GTile {
     static constexpr int MB = C / 32;
     static constexpr int RA = PA + 1;                   // A-fragment register ring (slots)
     static constexpr bool UNROLL_ALL = (KSX % RA) != 0;  // else: loop over taps, one tap's k-steps per iteration
+    // C = 32: a convolution's whole A operand is NQT * MR fragments = at most 88 VGPRs per lane (k = 11), so it is loaded ONCE per phase,
+    // ahead of it, and the MFMA loop carries no vector-memory instruction at all (see conv_phase_wreg)
+    static constexpr bool WREG = VTTS_WREG && UNROLL_ALL && NXC == 1 && NQT * MR * 4 <= 96;
     static constexpr int XPT = (ROWSX_MAX * SPR1 + THREADS - 1) / THREADS;
     static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;  // packed weights of one convolution
     static_assert(C % (WM * 32) == 0 && N1 % (WN * 32) == 0, "tile/wave mismatch");
@@ -151,6 +157,26 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         }
     };
     load_bias(a.bias);
+
+    // ---------------- C = 32: register-resident weights ----------------
+    // What the per-workgroup timelines show at C = 32 (tools/kbench, gpurun_out/r03_exp8/timeline.txt): the loops take 11.4k + 7.5k
+    // cycles for 2 x 2.8k cycles of MFMA — they crawl whenever the co-resident workgroup is in a memory phase, because every k-step
+    // (only 4 MFMAs = 128 cycles at one m-block) waits for a weight fragment that queues behind the partner's 36 KB of staging loads
+    // in the CU's one vector-memory pipeline; a 3-step ring is 384 cycles of cover against 5k-cycle bursts.  All of a convolution's
+    // fragments fit in registers here, so they are requested in ONE burst a phase ahead (c1's before the X tile is staged, c2's
+    // before epilogue 1) and the loop is ds_read + MFMA only.
+    constexpr int NQW = T::WREG ? NQT : 1;
+    bf16x8 aw[NQW][MR];
+    auto load_w_all = [&](const unsigned char* __restrict__ wconv) {
+        if constexpr (T::WREG) {
+            const uint4* __restrict__ ap = reinterpret_cast<const uint4*>(wconv) + (size_t)(wm * MR) * 64 + lane;
+#pragma unroll
+            for (int q = 0; q < NQT; ++q)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr) aw[q][mr] = __builtin_bit_cast(bf16x8, ap[(size_t)(q * MB + mr) * 64]);
+        }
+    };
+    load_w_all(static_cast<const unsigned char*>(a.wp));
 
     // ---------------- X tile (channel chunk xc): LeakyReLU + zero padding in registers, swizzled ds_write_b128 ----------------
     // XB = loads in flight per thread: all of them for the first chunk (nothing else is live yet), a few at a time for
@@ -392,6 +418,32 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         }
     };
 
+    // the same pass with the A operand in registers (T::WREG): one LDS fragment read per MFMA, nothing else in the loop
+    auto conv_phase_wreg = [&](int dl, auto sprb_tag) {
+        constexpr int SPRB = decltype(sprb_tag)::value;
+        bf16x8 bf[2][NR];
+        auto load_b = [&](int q, int par) {
+            const int tap = q / KSTEPS, ks = q % KSTEPS;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bf[par][nr] = *reinterpret_cast<const bf16x8*>(xt + tile_off<SPRB>(rowbase0 + tap * dl + nr * 32, ks * 2 + lh));
+        };
+        load_b(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+        for (int q = 0; q < NQT; ++q) {
+            if (q + 1 < NQT) load_b(q + 1, (q + 1) & 1);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q < NQW ? q : 0][mr], bf[q & 1][nr], q == 0 ? bblk[mr] : acc[mr][nr], 0, 0, 0);
+            for (int i = 0; i < MR * NR; ++i) {  // one fragment read behind each MFMA
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q + 1 < NQT && i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+
     // ---------------- phase 1: xt = c1(lrelu(x)); column n <-> xt time t0 - H2 + n; tap j reads X row n + j*dil ----------------
 #pragma unroll
     for (int xc = 0; xc < NXC; ++xc) {
@@ -400,12 +452,15 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             stage_x(xc, std::integral_constant<int, 4>{});
             __syncthreads();
         }
-        if (xc == 0)
+        if constexpr (T::WREG)
+            conv_phase_wreg(dil, std::integral_constant<int, SPR1>{});
+        else if (xc == 0)
             conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, 0, std::true_type{});
         else
             conv_phase(static_cast<const unsigned char*>(a.wp), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, xc * KSX, std::false_type{});
     }
     VTTS_TL(a, wg_lin, 2);
+    load_w_all(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES);  // T::WREG: c2's fragments, in flight under epilogue 1
     __syncthreads();  // B2: every wave is done reading the X tile
 
     // A lane's accumulators for one 32x32 block: column (time) l31, rows (channels) 8*rq + 4*lh + i, r = 4*rq + i.
@@ -479,7 +534,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #endif
         // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
         for (int u = tid; u < 2 * H2 * SPR2; u += THREADS) {
-            const int row = N1 + u / SPR2, c = u % SPR2;
+            const int row = N1 + u % (2 * H2), c = u / (2 * H2);  // consecutive lanes: consecutive rows of one slot (conflict-free in the blocked tiles)
             *reinterpret_cast<uint4*>(xt + tile_off<SPR2>(row, c)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
@@ -500,7 +555,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     }
     conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::false_type{});
 #else
-    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::true_type{});
+    if constexpr (T::WREG)
+        conv_phase_wreg(1, std::integral_constant<int, SPR2>{});
+    else
+        conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::true_type{});
 #endif
     VTTS_TL(a, wg_lin, 4);
 

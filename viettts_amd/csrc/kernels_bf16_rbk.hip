@@ -30,6 +30,13 @@
 
 #include "bf16_common.h"
 
+#ifndef VTTS_WREG  // register-resident weights (A/B switch)
+#define VTTS_WREG 1
+#endif
+#ifndef VTTS_WREG_RB_MAX  // ... for convolutions of at most this many VGPRs of fragments per lane: 56 = C = 32 at k = 3, 7 (k = 11: 88, spills beside the
+#define VTTS_WREG_RB_MAX 64  // running x; C = 64, k = 3: 96)
+#endif
+
 namespace vtts {
 
 template <int C_, int KS_, int W_, int WM_, int WN_, int PA_, int MINWG_>
@@ -52,6 +59,9 @@ struct RBTile {
     static constexpr int XPT = (W * SPR + THREADS - 1) / THREADS;
     static_assert(C % (WM * 32) == 0 && W % (WN * 32) == 0 && LDS_BYTES <= 160 * 1024, "window / LDS");
     static_assert(RA == 4 && (NQT % 4 == 0 || NQT % 4 == 2), "ring of 4; a phase starts at slot 0 or 2");
+    // C = 32: a convolution's A operand (NQT * MR fragments, <= 88 VGPRs) is loaded in one burst a phase ahead and the MFMA loops carry
+    // no vector-memory instruction (kernels_bf16_rbg.hip: GTile::WREG, same reason)
+    static constexpr bool WREG = VTTS_WREG && NQT * MR * 4 <= VTTS_WREG_RB_MAX;
 };
 
 template <class T>
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     // ---- guard rows of both tiles = 0 (never written again) ----
     for (int u = tid; u < 2 * 2 * GUARD * SPR; u += THREADS) {
         const int tile = u / (2 * GUARD * SPR), v = u % (2 * GUARD * SPR);
-        const int gr = v / SPR, c = v % SPR;
+        const int gr = v % (2 * GUARD), c = v / (2 * GUARD);  // consecutive lanes: consecutive rows of one slot (conflict-free in the blocked tiles, tile_off)
         const int row = gr < GUARD ? gr : W + gr;  // [0, GUARD) and [GUARD + W, ROWS)
         *reinterpret_cast<uint4*>((tile ? tT : tA) + tile_off<SPR>(row, c)) = make_uint4(0u, 0u, 0u, 0u);
     }
@@ -236,8 +246,48 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             step(NQT - 1, 1, false);
         }
     };
+    // T::WREG: convolution `conv`'s fragments in registers; requested with load_w_all(conv) a phase ahead
+    constexpr int NQW = T::WREG ? NQT : 1;
+    bf16x8 aw[NQW][MR];
+    auto load_w_all = [&](int conv) {
+        if constexpr (T::WREG) {
+            if (conv < 6) {
 #pragma unroll
-    for (int q = 0; q < PA; ++q) load_a(q, q % RA);  // the stream's first fragments, under the tile staging
+                for (int q = 0; q < NQT; ++q)
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) aw[q][mr] = __builtin_bit_cast(bf16x8, aptr[(size_t)((conv * NQT + q) * MB + mr) * 64]);
+            }
+        }
+    };
+    auto conv_phase_wreg = [&](const unsigned char* __restrict__ tile, int dl) {
+        bf16x8 bf[2][NR];
+        auto load_b = [&](int q, int par) {
+            const int tap = q / KSTEPS, ks = q % KSTEPS;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) bf[par][nr] = *reinterpret_cast<const bf16x8*>(tile + tile_off<SPR>(GUARD + col0 + nr * 32 + (tap - H) * dl, ks * 2 + lh));
+        };
+        load_b(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+        for (int q = 0; q < NQT; ++q) {
+            if (q + 1 < NQT) load_b(q + 1, (q + 1) & 1);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q < NQW ? q : 0][mr], bf[q & 1][nr], acc[mr][nr], 0, 0, 0);
+            for (int i = 0; i < MR * NR; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (q + 1 < NQT && i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+    };
+    if constexpr (T::WREG) {
+        load_w_all(0);
+    } else {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) load_a(q, q % RA);  // the stream's first fragments, under the tile staging
+    }
     // this lane's 16 values of block nr -> tile rows (8 consecutive channels per lane after the swap), masked outside [0, L)
     auto write_tile = [&](unsigned char* tile, int mr, int nr, unsigned p0, unsigned p1, unsigned q0, unsigned q1, int p) {
         const int row = GUARD + col0 + nr * 32;
@@ -257,7 +307,12 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     for (int pr = 0; pr < 3; ++pr) {
         const int dl = pr == 0 ? d0 : (pr == 1 ? d1 : d2);
         // ---- c1 over A ----
-        conv_phase(2 * pr, std::integral_constant<int, 0>{}, tA, dl);
+        if constexpr (T::WREG) {
+            conv_phase_wreg(tA, dl);
+            load_w_all(2 * pr + 1);  // c2's fragments, in flight under the epilogue
+        } else {
+            conv_phase(2 * pr, std::integral_constant<int, 0>{}, tA, dl);
+        }
         // ---- xt = lrelu(.) -> T ----
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
@@ -273,7 +328,12 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         init_acc(2 * pr + 1);
         __syncthreads();  // T written; every wave is done reading A
         // ---- c2 over T (rate 1) ----
-        conv_phase(2 * pr + 1, std::integral_constant<int, S2>{}, tT, 1);
+        if constexpr (T::WREG) {
+            conv_phase_wreg(tT, 1);
+            load_w_all(2 * pr + 2);  // the next pair's c1 (nothing after the last pair)
+        } else {
+            conv_phase(2 * pr + 1, std::integral_constant<int, S2>{}, tT, 1);
+        }
         // ---- x = c2 + x  (model.py:50) ----
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
@@ -368,10 +428,22 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     }
 }
 
+// window geometry (kernel-development switches, tools/ab_bench.sh): time steps per window, waves along time, workgroups per CU
+#ifndef VTTS_RB32_W
+#define VTTS_RB32_W 512
+#define VTTS_RB32_WN 4
+#define VTTS_RB32_WG 2
+#endif
+#ifndef VTTS_RB64_W
+#define VTTS_RB64_W 256
+#define VTTS_RB64_WN 4
+#define VTTS_RB64_WG 2
+#endif
 //                                     C   KS   W  WM WN PA MINWG
-template <int KS> using RB32 = RBTile<32, KS, 512, 1, 4, 3, 2>;
-template <int KS> using RB64 = RBTile<64, KS, 256, 1, 4, 3, 2>;
+template <int KS> using RB32 = RBTile<32, KS, VTTS_RB32_W, 1, VTTS_RB32_WN, 3, VTTS_RB32_WG>;
+template <int KS> using RB64 = RBTile<64, KS, VTTS_RB64_W, 1, VTTS_RB64_WN, 3, VTTS_RB64_WG>;
 template <int KS> using RB128 = RBTile<128, KS, 128, 2, 2, 3, 2>;
+constexpr bool RB64_ALL_K = RB64<11>::LDS_BYTES * VTTS_RB64_WG <= 160 * 1024 && VTTS_RB64_W - 2 * 60 >= 128;  // k = 7, 11 too once the window is wide enough
 
 template <class T>
 static hipError_t launch_rb(const BConvArgs& a, hipStream_t s) {
@@ -395,13 +467,15 @@ bool resblock_bf16_supported(int C, int K, const int* dils) {
     for (int i = 0; i < 3; ++i)
         if (dils[i] < 1 || dils[i] > 5) return false;
     if (C == 32) return K == 3 || K == 7 || K == 11;
+    if (C == 64 && RB64_ALL_K) return K == 3 || K == 7 || K == 11;
     return (C == 64 || C == 128) && K == 3;
 }
-// ... and where it is the faster choice (per ResBlock at B = 64 x T = 1024, rocprofv3, profiles/r01_h_fuse_policy.md):
-//   C = 32 : k = 3  1.21 ms vs 1.62 ms as three pair launches;  k = 7  2.27 vs 2.22;  k = 11  3.40 vs 3.08 (23 % of the window is margin)
+// ... and where it is the faster choice (per ResBlock at B = 64 x T = 1024, rocprofv3; round 1: profiles/r01_h_fuse_policy.md, round 3 after
+// the blocked LDS tiles and the un-packed VALU: gpurun_out/r03_exp6/fuse3_stats.md vs profiles/r03_b_kernel_stats.md):
+//   C = 32 : k = 3  1.17 ms vs 1.62 ms as three pair launches;  k = 7  2.07 vs 2.21 (round 1: 2.27 vs 2.22);  k = 11  3.20 vs 2.90 (23 % of the window is margin)
 //   C = 64 : k = 3  1.77 vs 2.29
-//   C = 128: k = 3  3.23 vs 3.07 (64 x 64 wave tiles double the weight-fragment traffic per MFMA; 19 % margin)
-bool resblock_bf16_preferred(int C, int K) { return K == 3 && (C == 32 || C == 64); }
+//   C = 128: k = 3  3.27 vs 3.12 (64 x 64 wave tiles double the weight-fragment traffic per MFMA; 19 % margin)
+bool resblock_bf16_preferred(int C, int K) { return (C == 32 && (K == 3 || K == 7)) || (C == 64 && K == 3); }
 
 // a.wp = [pair0 c1][pair0 c2][pair1 c1]...[pair2 c2], each one convolution in pair_g_pack_geom(C, K) order;
 // a.bias = 6 x [C]; a.dils = the three rates; a.x = stage input (raw), a.y = MRF accumulator / stage output
@@ -412,6 +486,10 @@ hipError_t launch_resblock_bf16(int C, int K, const BConvArgs& a, hipStream_t s)
             case 11: return launch_rb<RB32<11>>(a, s);
         }
     if (C == 64 && K == 3) return launch_rb<RB64<3>>(a, s);
+    if constexpr (RB64_ALL_K) {
+        if (C == 64 && K == 7) return launch_rb<RB64<7>>(a, s);
+        if (C == 64 && K == 11) return launch_rb<RB64<11>>(a, s);
+    }
     if (C == 128 && K == 3) return launch_rb<RB128<3>>(a, s);
     return hipErrorInvalidValue;
 }
