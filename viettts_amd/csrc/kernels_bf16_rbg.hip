@@ -42,6 +42,9 @@
 #define VTTS_RES_MFMA 0  // Correct and bit-stable, but NOT faster (round 3, profiles/r03_a_coissue_findings.md): -290 VALU per tile buy nothing
 #endif                   // because the requests that feed it are VMEM, which an MFMA stream on the same SIMD blocks just as it blocks the adds' loads
 
+#ifndef VTTS_RAWRES  // C = 32: the tile's raw rows kept in LDS as the residual (A/B switch)
+#define VTTS_RAWRES 1
+#endif
 #ifndef VTTS_WREG  // C = 32: the convolution's weights register-resident for the whole phase (A/B switch, tools/kbench)
 #define VTTS_WREG 1
 #endif
@@ -84,10 +87,17 @@ struct GTile {
     static_assert(C % XC == 0 && (NXC == 1 || !UNROLL_ALL), "channel chunking");
     static_assert(SPR1 == 4 || SPR1 == 8 || SPR1 == 16, "X row pitch 64..256 B");
     static_assert(SPR2 == 4 || SPR2 == 8 || SPR2 == 16 || SPR2 == 32, "xt row pitch 64..512 B");
-    static int lds_bytes(int dil) {  // rows in multiples of 16 (tile_off's blocks of 16 rows at C = 32 / 64)
+    // C = 32: the pair is bound by the CU's share of HBM (100 KB per tile at ~8 B per tick: profiles/r03_c_narrow_stage_findings.md), and a third
+    // of those bytes is the residual's second read of rows the staging pass has just had in registers: it keeps them, raw, in a second LDS
+    // region (32 KB; 69 KB with the X tile, still two workgroups per CU) and epilogue 2 adds them from there
+    static constexpr bool RAWRES = VTTS_RAWRES && NXC == 1 && C == 32;
+    static constexpr int RAW_BYTES = RAWRES ? tile_rows16(N1) * P1 : 0;
+    static __host__ __device__ constexpr int tile_bytes(int dil) {  // rows in multiples of 16 (tile_off's blocks of 16 rows at C = 32 / 64)
         const int bx = tile_rows16(N1 + 2 * H2 * dil) * P1, bt = tile_rows16(ROWST) * P2;
         return bx > bt ? bx : bt;
     }
+    static int lds_bytes(int dil) { return tile_bytes(dil) + RAW_BYTES; }
+    static_assert(tile_rows16(ROWSX_MAX) * P1 + RAW_BYTES <= 80 * 1024 || !RAWRES, "two workgroups per CU");
     static_assert(tile_rows16(ROWSX_MAX) * P1 <= 160 * 1024 && tile_rows16(ROWST) * P2 <= 160 * 1024, "LDS budget");
 };
 
@@ -100,6 +110,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* xt = lds;  // X tile, later the xt tile
+    [[maybe_unused]] unsigned char* const xraw = lds + (T::RAWRES ? T::tile_bytes(a.dil) : 0);  // T::RAWRES: raw rows t0 .. t0 + N1 - 1 (the residual)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -193,6 +204,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         const int row0 = (SPR1 >= 16 || !VTTS_TILE_BLOCKED) ? tid / SPR1 : wave * RW + lane % RW, c = (SPR1 >= 16 || !VTTS_TILE_BLOCKED) ? tid % SPR1 : lane / RW;
         auto act2 = [](unsigned u) { return lrelu01_pack(bf16_lo(u), bf16_hi(u)); };  // LRELU_SLOPE, model.py:5,46
         unsigned char* const lds0 = xt + tile_off<SPR1>(row0, c);  // unit i: + i * RPI * P1 (RPI is a multiple of 16: same swizzle / same place in its block)
+        // T::RAWRES: X-tile row r holds time t0 - H2 - h1 + r; rows of times t0 .. t0 + N1 - 1 also go, un-activated, to the residual region
+        [[maybe_unused]] auto keep_raw = [&](int r, int cc, const uint4& raw, bool live) {
+            const int rr = r - H2 - h1;
+            if (live && rr >= 0 && rr < N1) *reinterpret_cast<uint4*>(xraw + tile_off<SPR1>(rr, cc)) = raw;
+        };
         if (tx0 >= 0 && tx0 + XPT * RPI <= L) {
             // interior tile (all but the first / last of an utterance): no clamping, no masking, constant strides
             const unsigned short* __restrict__ g0 = xg + (size_t)(tx0 + row0) * C + xc * XC + c * 8;
@@ -209,6 +225,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     VTTS_TL(a, wg_lin, 8);
                 }
 #endif
+                if constexpr (T::RAWRES) {
+#pragma unroll
+                    for (int i = 0; i < XB; ++i) keep_raw(row0 + (i0 + i) * RPI, c, v[i], i0 + i < XPT);
+                }
 #pragma unroll
                 for (int i = 0; i < XB; ++i) {
                     v[i].x = act2(v[i].x);
@@ -238,6 +258,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
             for (int i = 0; i < XB; ++i) {
                 if (!okx[i]) v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (T::RAWRES) keep_raw(row0 + (i0 + i) * RPI, c, v[i], i0 + i < XPT);
                 v[i].x = act2(v[i].x);
                 v[i].y = act2(v[i].y);
                 v[i].z = act2(v[i].z);
@@ -619,7 +640,26 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 }
         }
 #else
-        add_rows(xg);                                                       // x = xt + x        (model.py:50)
+        if constexpr (T::RAWRES) {                                          // x = xt + x        (model.py:50), rows from the LDS copy
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int col = wn * (N1 / WN) + nr * 32 + l31;
+                        uint4 r = *reinterpret_cast<const uint4*>(xraw + tile_off<SPR1>(col, (wm * (C / T::WM) + mr * 32 + 16 * p) / 8 + lh));
+                        swap_pair(r.x, r.z);
+                        swap_pair(r.y, r.w);
+                        const int r0 = 8 * p;
+                        acc[mr][nr][r0 + 0] = vadd_raw(bf16_lo(r.x), acc[mr][nr][r0 + 0]); acc[mr][nr][r0 + 1] = vadd_raw(bf16_hi(r.x), acc[mr][nr][r0 + 1]);
+                        acc[mr][nr][r0 + 2] = vadd_raw(bf16_lo(r.y), acc[mr][nr][r0 + 2]); acc[mr][nr][r0 + 3] = vadd_raw(bf16_hi(r.y), acc[mr][nr][r0 + 3]);
+                        acc[mr][nr][r0 + 4] = vadd_raw(bf16_lo(r.z), acc[mr][nr][r0 + 4]); acc[mr][nr][r0 + 5] = vadd_raw(bf16_hi(r.z), acc[mr][nr][r0 + 5]);
+                        acc[mr][nr][r0 + 6] = vadd_raw(bf16_lo(r.w), acc[mr][nr][r0 + 6]); acc[mr][nr][r0 + 7] = vadd_raw(bf16_hi(r.w), acc[mr][nr][r0 + 7]);
+                    }
+        } else {
+            add_rows(xg);                                                   // x = xt + x        (model.py:50)
+        }
         if (a.acc_add != 0) add_rows(yg);                                   // xs += rb(x)       (model.py:118-120)
 #endif
         VTTS_TL(a, wg_lin, 12);
