@@ -121,6 +121,15 @@ int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint64_t* see
  */
 int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int B, int Fmax, uint8_t* keep_dev,
                                        void* stream);
+/*
+ * ... with the threefry layout as a parameter: threefry_partitionable = 0 is the entry point above; 1 is the layout JAX >= 0.5 uses by
+ * default (jax_threefry_partitionable=True: subkey i of a split and element c of a 32-bit draw are the cipher on the 64-bit index
+ * itself, a draw's word = y0 ^ y1).  The reference pins no JAX version (setup.py:6-19), so which stream a given checkpoint was
+ * sampled with at inference depends on the JAX it ran under.  Mode 1 is restated from recollection of jax/_src/prng.py
+ * (oracle/nat_oracle.py::jax_partitionable_*) and is NOT pinned by any known answer: use it knowingly.
+ */
+int vtts_nat_acoustic_keep_masks_haiku_mode(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int threefry_partitionable, int B,
+                                            int Fmax, uint8_t* keep_dev, void* stream);
 int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
                               const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
                               const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream);

@@ -321,13 +321,34 @@ def jax_legacy_uniform(key, n: int) -> np.ndarray:
     return ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
 
 
-def haiku_prenet_keep_masks(rng_key, n_frames: int, prenet_dim: int = 256) -> np.ndarray:
+# The same two primitives under ``jax_threefry_partitionable=True`` (the default from JAX 0.5 on; jax/_src/prng.py:
+# ``_threefry_split_foldlike`` and ``_threefry_random_bits_partitionable``), restated FROM RECOLLECTION of that file — no known
+# answer for this mode is quotable from memory and no JAX runs here, so this mode is **unpinned** (tests check device == this
+# restatement and that the two modes differ; nothing checks this restatement against JAX):
+#   split(key, n)[i]   = threefry2x32(key, (hi, lo) of the 64-bit index i)            -> the pair (y0, y1) IS subkey i
+#   bits(key, shape)   : element i (row-major index, 64 bit) -> threefry2x32(key, (hi(i), lo(i))), word = y0 ^ y1 (32-bit draws)
+def jax_partitionable_split(key, num: int = 2) -> np.ndarray:
+    idx = np.arange(num, dtype=np.uint32)
+    y0, y1 = threefry2x32_20(np.uint32(key[0]), np.uint32(key[1]), np.zeros(num, np.uint32), idx)
+    return np.stack([y0, y1], axis=1)
+
+
+def jax_partitionable_uniform(key, n: int) -> np.ndarray:
+    idx = np.arange(n, dtype=np.uint32)
+    y0, y1 = threefry2x32_20(np.uint32(key[0]), np.uint32(key[1]), np.zeros(n, np.uint32), idx)
+    bits = y0 ^ y1
+    return ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - np.float32(1.0)
+
+
+def haiku_prenet_keep_masks(rng_key, n_frames: int, prenet_dim: int = 256, partitionable: bool = False) -> np.ndarray:
     """``[n_frames, 2, prenet_dim]`` boolean keep masks of AcousticModel.inference's prenet dropout as the reference draws
-    them from ``rng_key`` (uint32 [2]: the checkpoint's ``rng``) — see the block comment above."""
+    them from ``rng_key`` (uint32 [2]: the checkpoint's ``rng``) — see the block comment above.  ``partitionable``: the layout of
+    ``jax_threefry_partitionable=True`` (JAX >= 0.5's default; unpinned, see above) instead of the classic one."""
     key = np.asarray(rng_key, dtype=np.uint32).reshape(2)
+    split, uniform = (jax_partitionable_split, jax_partitionable_uniform) if partitionable else (jax_legacy_split, jax_legacy_uniform)
     out = np.empty((n_frames, 2, prenet_dim), dtype=bool)
     for t in range(n_frames):
         for layer in range(2):
-            key, sub = jax_legacy_split(key, 2)
-            out[t, layer] = jax_legacy_uniform(sub, prenet_dim) < np.float32(0.5)
+            key, sub = split(key, 2)
+            out[t, layer] = uniform(sub, prenet_dim) < np.float32(0.5)
     return out

@@ -288,6 +288,15 @@ def test_device_haiku_masks_equal_the_reference_stream_restatement(acoustic):
         assert got.shape == (3, 41, 2, 256) and got.dtype == np.uint8
         for b in range(3):
             assert np.array_equal(got[b].astype(bool), want), (rng, b)
+    # the other counter layout (jax_threefry_partitionable, JAX >= 0.5's default; an unpinned restatement: oracle/nat_oracle.py): device ==
+    # restatement, and it IS another stream
+    for rng in ((0, 0), (123456789, 42)):
+        got = am.device_keep_masks_haiku(rng, 2, 29, partitionable=True).cpu().numpy()
+        want = no.haiku_prenet_keep_masks(np.array(rng, dtype=np.uint32), 29, 256, partitionable=True)
+        for b in range(2):
+            assert np.array_equal(got[b].astype(bool), want), (rng, b)
+        assert not np.array_equal(want, no.haiku_prenet_keep_masks(np.array(rng, dtype=np.uint32), 29, 256))
+        assert abs(float(want.mean()) - 0.5) < 0.02
     rng = np.array([2024, 7], dtype=np.uint32)
     toks = [[0, 5, 9, 3, 14, 22, 3, 0], [0, 31, 3, 0]]
     frames = [np.array([3.0, 2.5, 4.0, 0.0, 3.5, 2.0, 0.0, 2.0], np.float32), np.array([2.0, 5.5, 0.0, 3.0], np.float32)]

@@ -317,3 +317,25 @@ def test_checkpoint_with_haiku_and_jax_objects_loads_without_those_libraries(tmp
     weird = ck._absent_class("haiku._src.data_structures", "Mystery")({"a": 1}, {"b": 2})
     with pytest.raises(CheckpointFormatError, match="Mystery"):
         ck.to_plain(weird)
+
+
+def test_partitionable_threefry_layout_is_another_stream_with_the_same_schedule():
+    """jax_threefry_partitionable (JAX >= 0.5's default): an UNPINNED restatement (oracle/nat_oracle.py: no known answer for this mode is
+    quotable offline) — checked for what can be checked here: its defining property (element i of a draw and subkey i of a split depend
+    on i alone, not on the size of the draw: that is what "partitionable" means), the Haiku schedule on top of it, and that it is not the
+    classic stream."""
+    from oracle.nat_oracle import haiku_prenet_keep_masks, jax_legacy_uniform, jax_partitionable_split, jax_partitionable_uniform, threefry2x32_20
+
+    k = np.array([123456789, 42], dtype=np.uint32)
+    assert np.array_equal(jax_partitionable_uniform(k, 4)[:2], jax_partitionable_uniform(k, 2))  # prefix-stable: the classic layout is not
+    assert np.array_equal(jax_partitionable_split(k, 4)[:2], jax_partitionable_split(k, 2))
+    y0, y1 = threefry2x32_20(np.uint32(k[0]), np.uint32(k[1]), np.zeros(1, np.uint32), np.ones(1, np.uint32))
+    assert jax_partitionable_split(k, 2)[1].tolist() == [int(y0[0]), int(y1[0])]
+    assert not np.array_equal(jax_partitionable_uniform(k, 8), jax_legacy_uniform(k, 8))
+    m = haiku_prenet_keep_masks(k, 20, 256, partitionable=True)
+    assert m.shape == (20, 2, 256) and 0.47 < m.mean() < 0.53
+    assert np.array_equal(m[:5], haiku_prenet_keep_masks(k, 5, 256, partitionable=True))
+    key = k
+    for _ in range(3):
+        key, sub = jax_partitionable_split(key, 2)
+    assert np.array_equal(m[1, 0], jax_partitionable_uniform(sub, 256) < np.float32(0.5))

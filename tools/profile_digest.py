@@ -29,10 +29,12 @@ def short(name):
 
 def main():
     run, tag = sys.argv[1], sys.argv[2]
+    dt = sys.argv[3] if len(sys.argv) > 3 else "bf16"  # which engine's passes: trace/ + pmc/ (bf16) or trace_f32/ + pmc_f32/
+    sfx = "" if dt == "bf16" else "_" + dt
     from viettts_amd.csrc.build import _digest
 
     # ---- kernel trace: per-dispatch durations from the rocpd database --------------------------------------------------
-    dbs = glob.glob(os.path.join(run, "trace", "**", "*results.db"), recursive=True)
+    dbs = glob.glob(os.path.join(run, "trace" + sfx, "**", "*results.db"), recursive=True)
     per = defaultdict(list)
     if dbs:
         db = sqlite3.connect(dbs[0])
@@ -51,8 +53,8 @@ def main():
         timed = v[n // 3:] if n >= 3 and n % 3 == 0 else v  # bench --warmup 1 --steps 2: the first third of a kernel's launches is the warm-up pass
         stats[k] = {"calls": n, "avg_us_all": sum(v) / n / 1e3, "avg_us_timed": sum(timed) / len(timed) / 1e3, "timed_calls": len(timed)}
     tot = sum(s["avg_us_timed"] * s["timed_calls"] for s in stats.values())
-    with open(os.path.join(run, f"{tag}_kernel_stats.md"), "w") as f:
-        f.write(f"# {tag} — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32` (bf16, B=64 x T=1024); "
+    with open(os.path.join(run, f"{tag}{sfx}_kernel_stats.md"), "w") as f:
+        f.write(f"# {tag} — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32{' --dtype f32' if dt == 'f32' else ''}` ({dt}, B=64 x T=1024); "
                 f"source digest `{_digest()[:16]}`.  avg (timed) drops each kernel's warm-up-pass launches (first touch of the workspace).\n\n")
         f.write("| kernel | calls | avg us (all) | avg us (timed passes) | % of timed GPU time |\n|---|---:|---:|---:|---:|\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us_timed"] * kv[1]["timed_calls"]):
@@ -64,7 +66,7 @@ def main():
 
     # ---- counters ------------------------------------------------------------------------------------------------------
     acc = defaultdict(lambda: defaultdict(list))
-    for fcsv in glob.glob(os.path.join(run, "pmc", "**", "*counter_collection.csv"), recursive=True):
+    for fcsv in glob.glob(os.path.join(run, "pmc" + sfx, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fcsv)):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     kern = {}
@@ -87,10 +89,10 @@ def main():
             "avg_us_timed": st["avg_us_timed"] if st else None,
             "timed_calls": st["timed_calls"] if st else None,
         }
-    rb = {k: v for k, v in kern.items() if k.startswith("resblock_") and v["mfma_util"] is not None and v["avg_us_timed"]}
+    rb = {k: v for k, v in kern.items() if (k.startswith("resblock_") or k.startswith("conv1d_f32_mfma_k")) and v["mfma_util"] is not None and v["avg_us_timed"]}
     tw = (sum(v["mfma_util"] * v["avg_us_timed"] * v["timed_calls"] for v in rb.values()) /
           sum(v["avg_us_timed"] * v["timed_calls"] for v in rb.values())) if rb else None
-    with open(os.path.join(run, f"{tag}_pmc.md"), "w") as f:
+    with open(os.path.join(run, f"{tag}{sfx}_pmc.md"), "w") as f:
         f.write(f"# {tag} — PMC passes of the SAME bench command (one counter set per pass: SQ+GRBM | FETCH_SIZE | WRITE_SIZE+TCC hit/miss), source digest `{_digest()[:16]}`\n\n")
         f.write("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 x 1024 SIMDs); HBM GB = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE per launch; "
                 "GB/s = HBM bytes / the kernel-trace pass's average duration (timed passes).\n\n")
@@ -108,13 +110,13 @@ def main():
     out = {
         "source_digest": _digest(),
         "tag": tag,
-        "command": "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32  (bf16, B=64 x T=1024; kernel-trace pass + 3 --pmc passes, tools/profile_final.sh)",
+        "command": f"python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32{' --dtype f32' if dt == 'f32' else ''}  ({dt}, B=64 x T=1024; kernel-trace pass + --pmc passes, tools/profile_final.sh)",
         "time_weighted_mfma_util_resblock_kernels": tw,
         "kernels": kern,
     }
-    with open(os.path.join(run, "counters_bf16.json"), "w") as f:
+    with open(os.path.join(run, f"counters_{dt}.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(f"{tag}: {len(stats)} kernels traced, {len(kern)} with counters, time-weighted ResBlock MfmaUtil = {tw}")
+    print(f"{tag} {dt}: {len(stats)} kernels traced, {len(kern)} with counters, time-weighted ResBlock MfmaUtil = {tw}")
 
 
 if __name__ == "__main__":

@@ -77,6 +77,7 @@ NAT_EXPORTS = (
     "vtts_nat_acoustic_workspace_bytes",
     "vtts_nat_acoustic_keep_masks",
     "vtts_nat_acoustic_keep_masks_haiku",
+    "vtts_nat_acoustic_keep_masks_haiku_mode",
     "vtts_nat_acoustic_forward",
 )
 
@@ -207,6 +208,7 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_acoustic_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(sz)]),
         "vtts_nat_acoustic_keep_masks": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_keep_masks_haiku": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]),
+        "vtts_nat_acoustic_keep_masks_haiku_mode": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sigs.items():

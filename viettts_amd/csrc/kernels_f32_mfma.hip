@@ -36,6 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int round_up4(int v) { return (v + 3) & ~3; }
 constexpr int MAX_DIL = 5;  // resblock_dilation_sizes max in V1; larger rates fall back to the generic kernel
+constexpr int F32_XCD_MIN_TILES = 64;  // XCD-aware tile order of conv1d_f32_mfma_k from this many time tiles per grid row on
 
 // =================================================================================================
 // dilated Conv1d
@@ -76,10 +77,19 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    const int t0 = blockIdx.x * NT;
+    const int L = a.L;
+    // XCD-aware tile order (as the bf16 pair kernel, kernels_bf16_rbg.hip): workgroups go to the 8 XCDs round-robin in launch order, so on
+    // launches of at least F32_XCD_MIN_TILES tiles per row of the grid (gridDim.x then padded to a multiple of 8 by the launcher) XCD
+    // blockIdx.x % 8 takes a contiguous, balanced eighth of the time tiles: a tile's halo columns were staged by the same L2's previous tile
+    int tile = blockIdx.x;
+    if (gridDim.x >= F32_XCD_MIN_TILES) {
+        const int nt = (L + NT - 1) / NT, r = (int)((blockIdx.x + blockIdx.z) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
+        tile = lo + (int)(blockIdx.x >> 3);
+        if (tile >= hi) return;
+    }
+    const int t0 = tile * NT;
     const int m0 = blockIdx.y * MT + wm * (MT / T::WM);  // first output channel of this wave
     const int b = blockIdx.z;
-    const int L = a.L;
     const float slope = a.slope_in;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
 
@@ -208,6 +218,7 @@ static hipError_t launch_tile(const ConvArgs& a, hipStream_t s) {
     static DynLdsOnce once;  // per device (vtts_internal.h)
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv1d_f32_mfma_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
     dim3 grid((a.L + T::NT - 1) / T::NT, T::COUT / T::MT, a.B);
+    if ((int)grid.x >= F32_XCD_MIN_TILES) grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs; with gridDim.x a multiple of 8, workgroup (x, y, z) runs on XCD x % 8
     hipLaunchKernelGGL(conv1d_f32_mfma_k<T>, grid, dim3(256), T::LDS_BYTES, s, a);
     return hipGetLastError();
 }

@@ -735,27 +735,56 @@ __global__ void nat_keep_masks_k(const unsigned long long* __restrict__ seeds, u
 // (half = ceil(PN / 2)); keep <=> the word's top bit is clear.  Every sentence of a batch gets the same masks (the reference runs
 // every sentence from the same checkpoint key).  One block per frame: its threads walk the key chain to frame f together (wave-
 // uniform, <= 4 * (f + 1) ciphers), then thread (layer, c) draws its word and writes it to all B sentences.
-__global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, unsigned char* __restrict__ keep, int B, int Fmax, int PN) {
+// mode 1 = the layout of jax_threefry_partitionable=True (JAX >= 0.5's default; oracle/nat_oracle.py::jax_partitionable_*, restated from
+// recollection of jax/_src/prng.py and NOT pinned by any known answer): split(key, 2)[i] = cipher(key, (0, i)) as the pair
+// (y0, y1); a 32-bit draw of element c = y0 ^ y1 of cipher(S, (0, c)).
+// Only the block's first wave walks the key chain (2 f + 2 splits, wave-uniform) and hands the frame's two subkeys to the others
+// through LDS (round 2: every thread of the block walked it).
+__global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsigned char* __restrict__ keep, int B, int Fmax, int PN) {
+    __shared__ unsigned sub[4];  // s0[0], s1[0], s0[1], s1[1]
     const int f = blockIdx.x;
-    unsigned ka = k0, kb = k1, s0[2], s1[2];
-    for (int n = 0; n < 2 * f + 2; ++n) {
-        unsigned a0 = 0u, b0 = 2u, a1 = 1u, b1 = 3u;
-        threefry2x32_20(ka, kb, a0, b0);
-        threefry2x32_20(ka, kb, a1, b1);
-        ka = a0;  // split(key, 2)[0] = (y0[0], y0[1]) stays the sequence's key ...
-        kb = a1;
-        if (n >= 2 * f) {  // ... [1] = (y1[0], y1[1]) is handed out
-            s0[n - 2 * f] = b0;
-            s1[n - 2 * f] = b1;
+    if (threadIdx.x < 64) {
+        unsigned ka = k0, kb = k1;
+        for (int n = 0; n < 2 * f + 2; ++n) {
+            unsigned a0, b0, a1, b1;
+            if (mode == 0) {
+                a0 = 0u, b0 = 2u, a1 = 1u, b1 = 3u;  // counts iota(4) in halves: pairs (0, 2), (1, 3)
+                threefry2x32_20(ka, kb, a0, b0);
+                threefry2x32_20(ka, kb, a1, b1);
+                if (n >= 2 * f && threadIdx.x == 0) {  // [1] = (y1[0], y1[1]) is handed out
+                    sub[2 * (n - 2 * f)] = b0;
+                    sub[2 * (n - 2 * f) + 1] = b1;
+                }
+                ka = a0;  // split(key, 2)[0] = (y0[0], y0[1]) stays the sequence's key
+                kb = a1;
+            } else {
+                a0 = 0u, b0 = 0u, a1 = 0u, b1 = 1u;  // subkey i = cipher(key, (0, i))
+                threefry2x32_20(ka, kb, a0, b0);
+                threefry2x32_20(ka, kb, a1, b1);
+                if (n >= 2 * f && threadIdx.x == 0) {
+                    sub[2 * (n - 2 * f)] = a1;
+                    sub[2 * (n - 2 * f) + 1] = b1;
+                }
+                ka = a0;
+                kb = b0;
+            }
         }
     }
+    __syncthreads();
     const int half = (PN + 1) / 2;
     for (int u = threadIdx.x; u < 2 * PN; u += blockDim.x) {
         const int layer = u / PN, c = u % PN;
-        const int i = c < half ? c : c - half;
-        unsigned x0 = (unsigned)i, x1 = i + half < PN ? (unsigned)(i + half) : 0u;  // counters iota(PN) in two halves; an odd count is padded with one 0
-        threefry2x32_20(s0[layer], s1[layer], x0, x1);
-        const unsigned word = c < half ? x0 : x1;
+        unsigned word;
+        if (mode == 0) {
+            const int i = c < half ? c : c - half;
+            unsigned x0 = (unsigned)i, x1 = i + half < PN ? (unsigned)(i + half) : 0u;  // counters iota(PN) in two halves; an odd count is padded with one 0
+            threefry2x32_20(sub[2 * layer], sub[2 * layer + 1], x0, x1);
+            word = c < half ? x0 : x1;
+        } else {
+            unsigned x0 = 0u, x1 = (unsigned)c;
+            threefry2x32_20(sub[2 * layer], sub[2 * layer + 1], x0, x1);
+            word = x0 ^ x1;
+        }
         const unsigned char kp = (word >> 31) ? 0 : 1;  // uniform = (word >> 9 | 1.0f) - 1 < 0.5  <=>  top bit clear
         for (int b = 0; b < B; ++b) keep[(((size_t)b * Fmax + f) * 2 + layer) * PN + c] = kp;
     }
@@ -1127,16 +1156,22 @@ VTTS_API int vtts_nat_acoustic_keep_masks(const vtts_nat_acoustic* h, const uint
     if (e != hipSuccess) return failf(VTTS_ERR_HIP, "keep-mask launch failed: %s", hipGetErrorString(e));
     return VTTS_OK;
 }
-VTTS_API int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int B, int Fmax, uint8_t* keep_dev,
-                                                void* stream) {
+VTTS_API int vtts_nat_acoustic_keep_masks_haiku_mode(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int threefry_partitionable, int B, int Fmax,
+                                                     uint8_t* keep_dev, void* stream) {
     if (!h || !keep_dev) return failf(VTTS_ERR_INVALID, "null argument");
     if (B <= 0 || Fmax <= 0) return failf(VTTS_ERR_INVALID, "B and Fmax must be positive (got %d, %d)", B, Fmax);
+    if (threefry_partitionable != 0 && threefry_partitionable != 1) return failf(VTTS_ERR_INVALID, "threefry_partitionable must be 0 (classic layout) or 1");
     const int PN = h->cfg.prenet_dim;
-    hipLaunchKernelGGL(nat_keep_masks_haiku_k, dim3(Fmax), dim3(2 * PN < 1024 ? 2 * PN : 1024), 0, static_cast<hipStream_t>(stream), rng_key0, rng_key1, keep_dev,
-                       B, Fmax, PN);
+    const int threads = 2 * PN < 1024 ? (2 * PN < 64 ? 64 : 2 * PN) : 1024;
+    hipLaunchKernelGGL(nat_keep_masks_haiku_k, dim3(Fmax), dim3(threads), 0, static_cast<hipStream_t>(stream), rng_key0, rng_key1, threefry_partitionable,
+                       keep_dev, B, Fmax, PN);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return failf(VTTS_ERR_HIP, "keep-mask launch failed: %s", hipGetErrorString(e));
     return VTTS_OK;
+}
+VTTS_API int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint32_t rng_key0, uint32_t rng_key1, int B, int Fmax, uint8_t* keep_dev,
+                                                void* stream) {
+    return vtts_nat_acoustic_keep_masks_haiku_mode(h, rng_key0, rng_key1, 0, B, Fmax, keep_dev, stream);
 }
 VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
                                        const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,

@@ -16,6 +16,8 @@ seed per sentence, independent of batching: the throughput pipeline's choice); `
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -29,6 +31,19 @@ from .duration import HaikuDict, _lookup, _ptr
 def bernoulli_keep_masks(n_frames: int, seed: int, prenet_dim: int = 256) -> np.ndarray:
     """``[n_frames, 2, prenet_dim]`` boolean keep masks, P(keep) = 0.5 (hk.dropout(key, 0.5, x), model.py:97, :99)."""
     return np.random.default_rng(seed).random((n_frames, 2, prenet_dim)) >= 0.5
+
+
+_STREAM_LOGGED = set()
+
+
+def _log_stream_once(partitionable: bool) -> None:
+    """Which dropout mask stream the reference-faithful path draws (vietTTS/nat/text2mel.py:65-73 hands the checkpoint's rng to whatever JAX
+    is installed; the reference pins no version): said once, so that a mel that differs from a JAX >= 0.5 run is not a silent surprise."""
+    if partitionable not in _STREAM_LOGGED:
+        _STREAM_LOGGED.add(partitionable)
+        logging.getLogger("viettts_amd.nat").info(
+            "prenet dropout masks: jax.random threefry, %s layout, under dm-haiku's PRNGSequence key chain (set VTTS_JAX_THREEFRY_PARTITIONABLE=%d for the other one)",
+            "partitionable (JAX >= 0.5 default; unpinned restatement)" if partitionable else "classic (JAX < 0.5 default)", 0 if partitionable else 1)
 
 
 class AcousticModel:
@@ -115,17 +130,24 @@ class AcousticModel:
             _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks(self._h, _ptr(sd), B, int(Fmax), _ptr(keep), C.c_void_p(stream.cuda_stream)))
         return keep
 
-    def device_keep_masks_haiku(self, rng_key, B: int, Fmax: int) -> torch.Tensor:
+    def device_keep_masks_haiku(self, rng_key, B: int, Fmax: int, partitionable: Optional[bool] = None) -> torch.Tensor:
         """``[B, Fmax, 2, prenet_dim]`` uint8 keep masks as the REFERENCE draws them from the checkpoint's ``rng`` (a
-        jax.random.PRNGKey, uint32[2]): jax.random's classic threefry layout under dm-haiku's key chain (include/vtts_nat.h:
-        vtts_nat_acoustic_keep_masks_haiku; restated in oracle/nat_oracle.py::haiku_prenet_keep_masks).  The same masks for
-        every sentence, as every run of the reference starts from the same key."""
+        jax.random.PRNGKey, uint32[2]): jax.random's threefry under dm-haiku's key chain (include/vtts_nat.h:
+        vtts_nat_acoustic_keep_masks_haiku[_mode]; restated in oracle/nat_oracle.py::haiku_prenet_keep_masks).  The same masks for
+        every sentence, as every run of the reference starts from the same key.
+
+        ``partitionable``: which counter layout — False = the classic one (every JAX before 0.5, pinned by JAX's documented
+        known answers), True = ``jax_threefry_partitionable`` (JAX >= 0.5's default; restated from recollection, unpinned).  None
+        reads ``VTTS_JAX_THREEFRY_PARTITIONABLE`` (unset / 0 = classic).  The stream in use is logged once per process."""
+        if partitionable is None:
+            partitionable = os.environ.get("VTTS_JAX_THREEFRY_PARTITIONABLE", "0") not in ("", "0")
+        _log_stream_once(bool(partitionable))
         k = np.asarray(rng_key, dtype=np.uint32).reshape(2)
         keep = torch.empty((int(B), int(Fmax), 2, self.prenet_dim), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks_haiku(self._h, int(k[0]), int(k[1]), int(B), int(Fmax), _ptr(keep),
-                                                                             C.c_void_p(stream.cuda_stream)))
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_keep_masks_haiku_mode(self._h, int(k[0]), int(k[1]), int(bool(partitionable)), int(B), int(Fmax),
+                                                                                  _ptr(keep), C.c_void_p(stream.cuda_stream)))
         return keep
 
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],

@@ -118,4 +118,26 @@ def load_checkpoint(path) -> Dict[str, Any]:
         out[k] = {str(m): {str(n): np.asarray(a) for n, a in dict(v).items()} for m, v in dict(plain).items()}
     rng = to_plain(dic.get("rng"))
     out["rng"] = None if rng is None else np.asarray(rng)
+    _validate(path, out)
     return out
+
+
+def _validate(path, out) -> None:
+    """A recovered (possibly guessed, see to_plain) layout is accepted only if it LOOKS like a Haiku parameter tree: module names as Haiku
+    forms them, every leaf a real-valued array, the rng a 2-word key.  Names and shapes are then checked one by one against the
+    model's own parameter table when they are handed to the C ABI (set_param rejects unknown modules and wrong shapes, pack() a
+    missing array): nothing unrecognised gets as far as a forward pass."""
+    if not out["params"]:
+        raise CheckpointFormatError(f"{path}: 'params' is empty after unwrapping")
+    for k in ("params", "aux"):
+        for mod, leaves in out[k].items():
+            if not leaves or "/" not in mod and "~" not in mod and not mod.replace("_", "").isalnum():
+                raise CheckpointFormatError(f"{path}: {k}[{mod!r}] does not look like a Haiku module entry")
+            for name, arr in leaves.items():
+                if not isinstance(arr, np.ndarray) or arr.dtype.kind not in "fiu" or arr.dtype == object:
+                    raise CheckpointFormatError(f"{path}: {k}[{mod!r}][{name!r}] is not a numeric array ({type(arr).__name__}, dtype {getattr(arr, 'dtype', None)})")
+                if arr.dtype.kind == "f" and not np.isfinite(arr).all():
+                    raise CheckpointFormatError(f"{path}: {k}[{mod!r}][{name!r}] holds non-finite values")
+    rng = out["rng"]
+    if rng is not None and not (rng.shape == (2,) and rng.dtype.kind in "ui"):
+        raise CheckpointFormatError(f"{path}: 'rng' is not a jax.random.PRNGKey (uint32[2]): shape {rng.shape}, dtype {rng.dtype}")
