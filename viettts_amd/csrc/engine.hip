@@ -455,11 +455,14 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
         }
         HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
     }
-    // transposed convolutions: the register-streamed kernel where it is the faster one (fuse >= 1; fuse = 3: everywhere), else the
-    // first-generation 3-tap convolution.  Per launch at B = 64 x T = 1024 (rocprofv3, profiles/r02_b_*): ups_0 329 vs 422 us,
-    // ups_1 575 vs 985, ups_2 684 vs 687, ups_3 597 vs 455 — the two HBM-bound ones (128 -> 2 x 64, 64 -> 2 x 32) keep the old
-    // kernel, whose epilogue goes through LDS and stores whole rows (the new one stores 32 bytes per frame and instruction).
-    const bool ug_pref = l.bcls == BCLS_UP0 || l.bcls == BCLS_UP1 || h->opt_fuse >= 3;
+    // transposed convolutions: the register-streamed kernel (fuse >= 1), else the first-generation 3-tap convolution.  Per launch at B = 64 x
+    // T = 1024 (rocprofv3): ups_0 305 vs 422 us, ups_1 551 vs 985; ups_2 529 vs 688 and ups_3 422 vs 453 since round 3, when the two
+    // HBM-bound ones (128 -> 2 x 64, 64 -> 2 x 32) got an LDS-staged epilogue that stores whole rows (round 2: 684 / 597 us with 32-byte
+    // stores per frame and instruction, which is why they had stayed on the first-generation kernel; gpurun_out/r03_exp16).
+#ifndef VTTS_UG_ALL  // A/B switch: 0 = round 2's policy (ups_2 / ups_3 on the first-generation kernel)
+#define VTTS_UG_ALL 1
+#endif
+    const bool ug_pref = VTTS_UG_ALL || l.bcls == BCLS_UP0 || l.bcls == BCLS_UP1 || h->opt_fuse >= 3;
     const bool ug = l.kind == KIND_CONVT && l.has_ug && h->opt_fuse >= 1 && ug_pref && res == nullptr && acc_add == 0 && div == 1.0f;
     if (ug) a.wp = h->blob + l.off_ug;
     hipError_t e = ug ? launch_convt_g_bf16(l.bcls, a, s) : launch_conv_bf16(l.bcls, K, a, s);

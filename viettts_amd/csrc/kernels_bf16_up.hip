@@ -22,6 +22,10 @@
 
 #include "bf16_common.h"
 
+#ifndef VTTS_UP_STAGE_OUT  // LDS-staged, row-contiguous output of the two-chunk tiles (A/B switch)
+#define VTTS_UP_STAGE_OUT 1
+#endif
+
 namespace vtts {
 
 template <int CIN_, int M_, int N1_, int WM_, int WN_, int MR_, int PA_, int MINWG_>
@@ -44,6 +48,13 @@ struct UTile {
     static_assert(RA == 4 && UB % RA == 0 && KSTEPS % UB == 0, "ring slot / B parity are a step's position in its block");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     static_assert((NCH & (NCH - 1)) == 0, "the launcher splits the chunks over 1, 2, 4 ... workgroups");
+    // ups_2 / ups_3 (two chunks, M = Cin): the epilogue above stores 32 bytes per frame and instruction (an output row is M * 2 = 128 /
+    // 256 bytes, a lane owns 16 of them), which is what kept these two HBM-bound layers on the first-generation kernel (round 2: 684 vs
+    // 687 us, 597 vs 455).  Both chunks' packed results fit in registers (64 VGPRs), so they are held until the last chunk is done, go
+    // through the — by then dead — input tile in LDS, and leave as whole rows: a wave stores 1 KiB contiguous per instruction.
+    static constexpr int SPRO = M / 8;                  // 16-byte slots per OUTPUT row
+    static constexpr bool STAGE_OUT = VTTS_UP_STAGE_OUT && NCH == 2 && tile_rows16(N1) * M * 2 <= LDS_BYTES && NCH * MR * NR * 8 <= 64 &&
+                                      (N1 * SPRO) % THREADS == 0;
 };
 
 template <class T>
@@ -170,8 +181,8 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     for (int s = 0; s < PA; ++s) load_a(c_lo * NQ + s, s % RA);
     load_bias(c_lo);
 
-#pragma unroll 1
-    for (int c = c_lo; c < c_hi; ++c) {
+    // one chunk: its two taps' MFMAs, then `sink(mr, p, nr, rb, t, packed)` per 8 output rows of a frame
+    auto run_chunk = [&](int c, bool more, auto&& sink) {
         const int h = c >= NCH / 2 ? 1 : 0;
         {
             unsigned ta, xs;
@@ -204,9 +215,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         block(0, std::true_type{});
 #pragma unroll 1
         for (int bi = 1; bi < NQ / UB; ++bi) block(bi, std::false_type{});
-        if (c + 1 < c_hi) load_bias(c + 1);  // lands while this chunk's epilogue runs
+        if (more) load_bias(c + 1);  // lands while this chunk's epilogue runs
 
-        // ---------------- epilogue: [consumer's LeakyReLU] -> bf16, 16-byte stores: row (phase, co) of frame t0 + n ----------------
+        // ---------------- epilogue: [consumer's LeakyReLU] -> bf16, 8 consecutive rows (phase, co) of frame t0 + n per lane ----------------
         const float s_out = a.slope_out;
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -227,11 +238,52 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     unsigned q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
                     swap_pair(p0, q0);
                     swap_pair(p1, q1);
-                    if (t < L) *reinterpret_cast<uint4*>(yg + (size_t)t * M + rb + 8 * lh) = make_uint4(p0, p1, q0, q1);
+                    sink(mr, p, nr, rb, t, make_uint4(p0, p1, q0, q1));
                 }
             }
         }
+    };
+    auto store_direct = [&](int, int, int, int rb, int t, const uint4& v) {  // 16-byte stores straight from the accumulator layout
+        if (t < L) *reinterpret_cast<uint4*>(yg + (size_t)t * M + rb + 8 * lh) = v;
+    };
+
+    if constexpr (T::STAGE_OUT) {
+        if (gridDim.y == 1) {  // both chunks in this workgroup
+            constexpr int SPRO = T::SPRO;
+            uint4 pk[2][MR][2][NR];
+            run_chunk(0, true, [&](int mr, int p, int nr, int, int, const uint4& v) { pk[0][mr][p][nr] = v; });
+            run_chunk(1, false, [&](int mr, int p, int nr, int, int, const uint4& v) { pk[1][mr][p][nr] = v; });
+            __syncthreads();  // every wave is done reading the input tile: it becomes the output tile [frame][M], same tile_off layout
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) {
+                            const int n = wn * (N1 / WN) + nr * 32 + l31;
+                            const int slot = (ci * MC + (wm * MR + mr) * 32 + 16 * p) / 8 + lh;
+                            *reinterpret_cast<uint4*>(xt + tile_off<SPRO>(n, slot)) = pk[ci][mr][p][nr];
+                        }
+            __syncthreads();
+            constexpr int UPT = N1 * SPRO / THREADS;  // whole rows out: consecutive lanes = consecutive 16-byte units of consecutive frames
+            uint4 ov[UPT];
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int u = tid + i * THREADS;
+                ov[i] = *reinterpret_cast<const uint4*>(xt + tile_off<SPRO>(u / SPRO, u % SPRO));
+            }
+#pragma unroll
+            for (int i = 0; i < UPT; ++i) {
+                const int u = tid + i * THREADS, n = u / SPRO;
+                if (t0 + n < L) *reinterpret_cast<uint4*>(yg + (size_t)(t0 + n) * M + (u % SPRO) * 8) = ov[i];
+            }
+            return;
+        }
     }
+#pragma unroll 1
+    for (int c = c_lo; c < c_hi; ++c) run_chunk(c, c + 1 < c_hi, store_direct);
 }
 
 // ---- tile table (Cin, rows = stride * Cout, frames per workgroup, waves, m-blocks per wave) ------------------------------
