@@ -180,7 +180,7 @@ int build_layers_bf16(vtts_hifigan* h) {
             l.wb_bytes = bf16_packed_bytes(g);
             l.off_wb = off;
             off = align_up(off + l.wb_bytes, 256);
-            if (l.kind == KIND_CONVT) {
+            if (l.kind == KIND_CONVT || (is_pre && l.bcls == BCLS_PRE && l.cin == 80)) {  // the register-streamed kernel's packing (kernels_bf16_up.hip; its conv_pre tile is the 80-mel one)
                 l.has_ug = true;
                 l.ug_bytes = bf16_packed_bytes(convt_g_pack_geom(l.bcls));
                 l.off_ug = off;
@@ -463,7 +463,8 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
 #define VTTS_UG_ALL 1
 #endif
     const bool ug_pref = VTTS_UG_ALL || l.bcls == BCLS_UP0 || l.bcls == BCLS_UP1 || h->opt_fuse >= 3;
-    const bool ug = l.kind == KIND_CONVT && l.has_ug && h->opt_fuse >= 1 && ug_pref && res == nullptr && acc_add == 0 && div == 1.0f;
+    // conv_pre (80 -> 512, k = 7, fp32 mel in) runs on the same kernel since round 3 (7 taps per chunk, rows converted while staging)
+    const bool ug = (l.kind == KIND_CONVT || l.bcls == BCLS_PRE) && l.has_ug && h->opt_fuse >= 1 && ug_pref && res == nullptr && acc_add == 0 && div == 1.0f;
     if (ug) a.wp = h->blob + l.off_ug;
     hipError_t e = ug ? launch_convt_g_bf16(l.bcls, a, s) : launch_conv_bf16(l.bcls, K, a, s);
     if (prof) {
@@ -1110,6 +1111,7 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
                 if (l.has_ug) bf16_pack(wc.data(), l.cin, convt_g_pack_geom(l.bcls), reinterpret_cast<unsigned short*>(host.data() + l.off_ug));
             } else {
                 bf16_pack(l.w.data(), l.cin, g, reinterpret_cast<unsigned short*>(host.data() + l.off_wb));
+                if (l.has_ug) bf16_pack(l.w.data(), l.cin, convt_g_pack_geom(l.bcls), reinterpret_cast<unsigned short*>(host.data() + l.off_ug));  // conv_pre
             }
         }
         for (size_t i = 0; i + 1 < h->layers.size(); ++i) {

@@ -28,23 +28,33 @@
 
 namespace vtts {
 
-template <int CIN_, int M_, int N1_, int WM_, int WN_, int MR_, int PA_, int MINWG_>
+// TAPS / HALVES: the transposed convolutions run two taps per chunk, rows of the first half of the chunks on frames (q - 1, q), the others on
+// (q, q + 1) (HALVES); conv_pre (Conv1d 80 -> 512, k = 7, model.py:83,110) is the same structure with all TAPS = 7 taps in every chunk, frames
+// q - 3 .. q + 3, and its fp32 mel rows (CINR = 80 channels) converted to bf16 while staging (INF32; channels 80 .. 127 of the tile are zero and
+// meet zero weights).
+template <int CIN_, int M_, int N1_, int WM_, int WN_, int MR_, int PA_, int MINWG_, int TAPS_ = 2, bool HALVES_ = true, int CINR_ = CIN_, bool INF32_ = false>
 struct UTile {
     static constexpr int CIN = CIN_, M = M_, N1 = N1_, WM = WM_, WN = WN_, MR = MR_, PA = PA_, MINWG = MINWG_;
+    static constexpr int TAPS = TAPS_, CINR = CINR_;
+    static constexpr bool HALVES = HALVES_, INF32 = INF32_;
+    static constexpr int HL = HALVES ? 1 : (TAPS - 1) / 2;   // tile row 0 holds frame t0 - HL
+    static constexpr int PT = HALVES ? 3 : TAPS;             // taps in the packed weights (the transposed convolutions' 3-tap form)
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int NR = N1 / WN / 32;
     static constexpr int MC = WM * MR * 32;             // output rows per chunk
     static constexpr int NCH = M / MC;                  // chunks; the first NCH / 2 read frames (q - 1, q), the others (q, q + 1)
     static constexpr int SPR = CIN / 8, P = CIN * 2;    // 16-byte slots / bytes per tile row
-    static constexpr int ROWS = N1 + 2;
+    static constexpr int ROWS = N1 + (HALVES ? 2 : TAPS - 1);
     static constexpr int KSTEPS = CIN / 16;             // k-steps per tap
-    static constexpr int NQ = 2 * KSTEPS;               // k-steps per chunk (two taps)
+    static constexpr int NQ = TAPS * KSTEPS;            // k-steps per chunk
     static constexpr int MB = M / 32;
     static constexpr int RA = PA + 1;
     static constexpr int UB = KSTEPS < 8 ? KSTEPS : 8;  // k-steps per block: a block never straddles taps
     static constexpr int XPT = (ROWS * SPR + THREADS - 1) / THREADS;
     static constexpr int LDS_BYTES = ROWS * P;
-    static_assert(N1 % (WN * 32) == 0 && M % MC == 0 && (M / 2) % MC == 0, "chunks must not straddle the two halves");
+    static_assert(N1 % (WN * 32) == 0 && M % MC == 0 && (!HALVES || (M / 2) % MC == 0), "chunks must not straddle the two halves");
+    static_assert(HALVES ? TAPS == 2 : (TAPS % 2 == 1), "two taps per half, or a centred odd convolution");
+    static_assert(!INF32 || (CINR % 8 == 0 && CINR <= CIN), "fp32 rows are converted 8 channels at a time");
     static_assert(RA == 4 && UB % RA == 0 && KSTEPS % UB == 0, "ring slot / B parity are a step's position in its block");
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups per CU");
     static_assert((NCH & (NCH - 1)) == 0, "the launcher splits the chunks over 1, 2, 4 ... workgroups");
@@ -53,7 +63,7 @@ struct UTile {
     // 687 us, 597 vs 455).  Both chunks' packed results fit in registers (64 VGPRs), so they are held until the last chunk is done, go
     // through the — by then dead — input tile in LDS, and leave as whole rows: a wave stores 1 KiB contiguous per instruction.
     static constexpr int SPRO = M / 8;                  // 16-byte slots per OUTPUT row
-    static constexpr bool STAGE_OUT = VTTS_UP_STAGE_OUT && NCH == 2 && tile_rows16(N1) * M * 2 <= LDS_BYTES && NCH * MR * NR * 8 <= 64 &&
+    static constexpr bool STAGE_OUT = VTTS_UP_STAGE_OUT && HALVES && NCH == 2 && tile_rows16(N1) * M * 2 <= LDS_BYTES && NCH * MR * NR * 8 <= 64 &&
                                       (N1 * SPRO) % THREADS == 0;
 };
 
@@ -76,7 +86,8 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int Lp = a.L;
     const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid input rows of this utterance (ragged batches)
     if (t0 >= L) return;
-    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * Lp * CIN;
+    const unsigned short* __restrict__ xg = static_cast<const unsigned short*>(a.x) + (size_t)b * Lp * CIN;  // bf16 input rows (!INF32)
+    [[maybe_unused]] const float* __restrict__ xg32 = static_cast<const float*>(a.x) + (size_t)b * Lp * T::CINR;  // fp32 input rows (INF32: conv_pre's mel)
     unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * Lp * M;
 
     // ---------------- input tile: frames t0 - 1 .. t0 + N1 (zero outside the utterance: lax "SAME"), swizzled ds_write_b128 ----------------
@@ -96,10 +107,18 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 const int u = tid + (i0 + i) * THREADS;
                 row[i] = u / SPR;
                 c[i] = u % SPR;
-                const int t = t0 - 1 + row[i];
+                const int t = t0 - T::HL + row[i];
                 ok[i] = u < ROWS * SPR && t >= 0 && t < L;
                 const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-                v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * CIN + c[i] * 8);
+                if constexpr (T::INF32) {  // 8 fp32 channels -> 4 bf16 pairs (round to nearest even, as every other producer of the bf16 path)
+                    const bool real = c[i] * 8 < T::CINR;
+                    const float4 lo = *reinterpret_cast<const float4*>(xg32 + (size_t)tc * T::CINR + (real ? c[i] * 8 : 0));
+                    const float4 hi = *reinterpret_cast<const float4*>(xg32 + (size_t)tc * T::CINR + (real ? c[i] * 8 + 4 : 4));
+                    v[i] = make_uint4(pack_bf16x2(lo.x, lo.y), pack_bf16x2(lo.z, lo.w), pack_bf16x2(hi.x, hi.y), pack_bf16x2(hi.z, hi.w));
+                    ok[i] = ok[i] && real;
+                } else {
+                    v[i] = *reinterpret_cast<const uint4*>(xg + (size_t)tc * CIN + c[i] * 8);
+                }
             }
 #pragma unroll
             for (int i = 0; i < XB; ++i) {
@@ -114,9 +133,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     }
     __syncthreads();
 
-    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, 3 * CIN * M * 2, 0x00020000);
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, T::PT * CIN * M * 2, 0x00020000);
     const unsigned a_voff = (unsigned)((wm * MR) * 64 + lane) * 16;  // lane's bytes inside a k-step's [MB][64][16 B], chunk 0
-    const int rowbase0 = wn * (N1 / WN) + l31;                         // this lane's column of block 0 = tile row of frame q - 1
+    const int rowbase0 = wn * (N1 / WN) + l31;                         // this lane's column of block 0 = tile row of frame q - HL
 
     f32x16 acc[MR][NR];
     f32x16 bblk[MR];
@@ -138,7 +157,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     auto load_a = [&](int g, int slot) {
         const int gc = g < NCH * NQ ? g : NCH * NQ - 1;  // the last look-aheads re-read the last step (inside the blob)
         const int c = gc / NQ, sidx = gc - c * NQ;
-        const int h = c >= NCH / 2 ? 1 : 0;
+        const int h = T::HALVES && c >= NCH / 2 ? 1 : 0;
         const int f = h + sidx / KSTEPS, ks = sidx % KSTEPS;
         const int soff = ((f * KSTEPS + ks) * MB + c * (MC / 32)) * 1024;
 #pragma unroll
@@ -183,7 +202,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 
     // one chunk: its two taps' MFMAs, then `sink(mr, p, nr, rb, t, packed)` per 8 output rows of a frame
     auto run_chunk = [&](int c, bool more, auto&& sink) {
-        const int h = c >= NCH / 2 ? 1 : 0;
+        const int h = T::HALVES && c >= NCH / 2 ? 1 : 0;
         {
             unsigned ta, xs;
             tap_terms(h, ta, xs);
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             unsigned ta, xs, tn, xn;
             tap_terms(h + tp, ta, xs);
             const bool wrap = ksb + UB >= KSTEPS;  // the block's last look-ahead B fragment is the next tap's first
-            tap_terms(h + (wrap ? (tp < 1 ? tp + 1 : 1) : tp), tn, xn);
+            tap_terms(h + (wrap ? (tp + 1 < T::TAPS ? tp + 1 : T::TAPS - 1) : tp), tn, xn);
             const int ksn = wrap ? 0 : ksb + UB;
 #pragma unroll
             for (int i = 0; i < UB; ++i) {
@@ -292,6 +311,7 @@ using UT0 = UTile<512, 2048, 64, 4, 1, 2, 3, 2>;   // ups_0: 512 -> 8 x 256, k =
 using UT1 = UTile<256, 1024, 128, 4, 1, 2, 3, 2>;  // ups_1: 256 -> 8 x 128, k = 16   (LDS 65 KiB)
 using UT2 = UTile<128, 128, 256, 1, 4, 2, 3, 2>;   // ups_2: 128 -> 2 x 64, k = 4     (LDS 64.5 KiB)
 using UT3 = UTile<64, 64, 512, 1, 4, 1, 3, 2>;     // ups_3: 64 -> 2 x 32, k = 4      (LDS 64.3 KiB)
+using UTP = UTile<128, 512, 128, 4, 1, 2, 3, 2, 7, false, 80, true>;  // conv_pre: 80 (-> 128) -> 512, k = 7, fp32 mel in (LDS 33.5 KiB)
 
 template <class T>
 static hipError_t launch_u(const BConvArgs& a, hipStream_t s) {
@@ -313,6 +333,7 @@ hipError_t launch_convt_g_bf16(int cls, const BConvArgs& a, hipStream_t s) {
         case BCLS_UP1: return launch_u<UT1>(a, s);
         case BCLS_UP2: return launch_u<UT2>(a, s);
         case BCLS_UP3: return launch_u<UT3>(a, s);
+        case BCLS_PRE: return launch_u<UTP>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -323,13 +344,15 @@ BPackGeom convt_g_pack_geom(int cls) {
         case BCLS_UP1: return BPackGeom{256, 256, 1024, 3, 1024, 1};
         case BCLS_UP2: return BPackGeom{128, 128, 128, 3, 128, 1};
         case BCLS_UP3: return BPackGeom{64, 64, 64, 3, 64, 1};
+        case BCLS_PRE: return BPackGeom{128, 128, 512, 7, 512, 1};  // the plain convolution's 7 taps, input channels padded 80 -> 128 with zeros
     }
     return BPackGeom{0, 0, 0, 0, 0, 0};
 }
 
 const char* convt_g_kernel_name(int cls) {
     static thread_local char buf[64];
-    snprintf(buf, sizeof(buf), "convt_g_bf16_k<UTile<%d,", cls == BCLS_UP0 ? 512 : cls == BCLS_UP1 ? 256 : cls == BCLS_UP2 ? 128 : 64);
+    if (cls == BCLS_PRE) snprintf(buf, sizeof(buf), "convt_g_bf16_k<UTile<128, 512,");
+    else snprintf(buf, sizeof(buf), "convt_g_bf16_k<UTile<%d,", cls == BCLS_UP0 ? 512 : cls == BCLS_UP1 ? 256 : cls == BCLS_UP2 ? 128 : 64);
     return buf;
 }
 
