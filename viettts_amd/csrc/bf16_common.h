@@ -29,6 +29,14 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __builtin_bit_cast
 // accumulators in epilogue 1 (tools/kbench check: err/tol 1.27 .. 26).
 __device__ __forceinline__ float vmul_raw(float a, float b) { return a * b; }
 __device__ __forceinline__ float vadd_raw(float a, float b) { return a + b; }
+// MRF mean (model.py:121 `x = xs / num_kernels`) in the bf16 kernels: a multiplication by the reciprocal, formed once per thread.  The fp32
+// engine divides (it answers to the 1e-4 bar); here the value is rounded to bf16 right afterwards, a product and a quotient differ by at
+// most one fp32 ulp (2^-16 of a bf16 ulp), and an IEEE division is 8 VALU instructions per element (v_div_scale x 2, v_rcp, 3 fma,
+// v_div_fmas, v_div_fixup: ~1000 per tile and wave on the four launches per pass that end a stage — they ran 10-13 % behind their siblings).
+#ifndef VTTS_MRF_DIV  // A/B switch: 1 = round 2's IEEE division per element
+#define VTTS_MRF_DIV 0
+#endif
+__device__ __forceinline__ float mrf_recip(float div) { return 1.0f / div; }
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v >= 0.0f ? v : vmul_raw(v, s); }
 // slope 0.1 < 1: leaky_relu(v) = max(v, 0.1 v) — identical values (v >= 0: v >= 0.1 v; v < 0: 0.1 v > v), one op fewer
 // max(a, b) as ONE v_max_f32: fmaxf() makes hipcc canonicalise (v_max_f32 x, x, x) every operand it cannot prove is not a

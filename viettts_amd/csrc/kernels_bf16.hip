@@ -259,6 +259,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
     // ---- epilogue 2: coalesced pass, 8 channels (16 bytes of bf16) per thread-iteration
     constexpr int UPR = MT / 8;  // units per row
     const float s_out = a.slope_out;
+    const float rdiv = mrf_recip(a.div);
     unsigned short* __restrict__ y = static_cast<unsigned short*>(a.y);
     const unsigned short* __restrict__ res = static_cast<const unsigned short*>(a.res);
     for (int u = tid; u < NT * UPR; u += THREADS) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(T::THREADS) void conv_bf16_k(BConvArgs a) {
         }
         if (a.div != 1.0f) {  // x = xs / num_kernels  (model.py:121)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] / a.div;
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * rdiv;
         }
         if (s_out != 1.0f) {  // the (only) consumer's LeakyReLU, applied once by the producer
 #pragma unroll

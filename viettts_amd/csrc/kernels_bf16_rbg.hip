@@ -587,6 +587,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     {
         const float s_out = a.slope_out;
         const float dv = a.div;
+        const float rdv = mrf_recip(dv);
         unsigned short* __restrict__ yg = static_cast<unsigned short*>(a.y) + (size_t)b * Lp * C;
         // rows of a [B][L][C] tensor in the swapped accumulator layout: all requests first, one wait
         auto add_rows = [&](const unsigned short* __restrict__ src) {
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     for (int e = 0; e < 8; ++e) v[e] = acc[mr][nr][8 * p + e];
                     if (dv != 1.0f) {  // x = xs / num_kernels  (model.py:121)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] / dv;
+                        for (int e = 0; e < 8; ++e) v[e] = VTTS_MRF_DIV ? v[e] / dv : v[e] * rdv;
                     }
                     if (s_out != 1.0f) {  // the (only) consumer's LeakyReLU, applied once by the producer
 #pragma unroll

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     {
         const float s_out = a.slope_out;
         const float dv = a.div;
+        const float rdv = mrf_recip(dv);
         const bool acc_add = a.acc_add != 0;
         // the residual registers are dead now: the MRF accumulator rows take their place (all requests first, one wait)
         if (acc_add) {  // xs += rb(x)  (model.py:118-120)
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     }
                     if (dv != 1.0f) {  // x = xs / num_kernels  (model.py:121)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = v[e] / dv;
+                        for (int e = 0; e < 8; ++e) v[e] = VTTS_MRF_DIV ? v[e] / dv : v[e] * rdv;
                     }
                     if (s_out != 1.0f) {  // the consumer's LeakyReLU (model.py:112 / :122), applied once by the producer
 #pragma unroll

@@ -105,7 +105,7 @@ struct BConvArgs {
     float slope_out;      // LeakyReLU applied to the stored output (the consumer's activation), 1 = none
     int acc_add;          // y = y + v   (MRF accumulate)
     int tile_pref;        // fused-pair tile width: 0 = by launch size, 1 = wide, 2 = narrow (option "tiles"; tests run both on short inputs)
-    float div;            // then v / div (MRF mean), 1 = none
+    float div;            // then the MRF mean v / div as v * (1 / div) (bf16_common.h: mrf_recip), 1 = none
     unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE): per-workgroup s_memtime stamps; else unused
 };
 
