@@ -37,7 +37,14 @@ __device__ __forceinline__ float vadd_raw(float a, float b) { return a + b; }
 #define VTTS_MRF_DIV 0
 #endif
 __device__ __forceinline__ float mrf_recip(float div) { return 1.0f / div; }
-__device__ __forceinline__ float lrelu_f(float v, float s) { return v >= 0.0f ? v : vmul_raw(v, s); }
+// LeakyReLU with a slope in (0, 1] (the model's: 0.1, 0.01, model.py:5,122; the engine rejects others): max(v, s v) — the same value as the
+// compare-and-select form for every finite v (v >= 0: s v <= v; v < 0: s v > v), two VALU instructions instead of three
+__device__ __forceinline__ float lrelu_f(float v, float s) {
+    float r;
+    const float m = vmul_raw(v, s);
+    asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
 // slope 0.1 < 1: leaky_relu(v) = max(v, 0.1 v) — identical values (v >= 0: v >= 0.1 v; v < 0: 0.1 v > v), one op fewer
 // max(a, b) as ONE v_max_f32: fmaxf() makes hipcc canonicalise (v_max_f32 x, x, x) every operand it cannot prove is not a
 // signalling NaN — one extra VALU instruction per element of the staging and epilogue phases, and those share the SIMD's

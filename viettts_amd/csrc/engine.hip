@@ -1329,6 +1329,8 @@ VTTS_API int vtts_hifigan_run_module(vtts_hifigan* h, const char* key, const flo
     const bool is_pre = (l == &h->layers[h->idx_pre]);
     const bool is_post = (l == &h->layers[h->idx_post]);
     if (h->dtype == VTTS_BF16) {
+        // the bf16 kernels form LeakyReLU as max(v, slope * v) (bf16_common.h: lrelu_f), valid for slopes in (0, 1]: the model's are 0.1 and 0.01
+        if (!(slope_in > 0.0f && slope_in <= 1.0f)) return fail(VTTS_ERR_INVALID, "run_module(): slope_in must lie in (0, 1] on a bf16 handle (got %g)", slope_in);
         // test hook: fp32 channels-last in/out, converted through temporary bf16 buffers
         hipStream_t st = static_cast<hipStream_t>(stream);
         const size_t nx = (size_t)B * L * l->cin, ny = (size_t)B * L * (l->kind == KIND_CONVT ? l->stride : 1) * l->cout;
