@@ -131,6 +131,29 @@ def test_upsample_kat_bf16(gen, v1_params, dev, i, fuse, L):
     assert np.abs(y - ref).max() <= 2.0 ** -8 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("i", [2, 3])
+def test_upsample_kat_bf16_large_launch_staged_epilogue(gen, v1_params, dev, i):
+    """ups_2 / ups_3 on a launch of >= 512 tiles: the register-streamed kernel then keeps both row chunks in one workgroup and stores them
+    through LDS as whole rows (kernels_bf16_up.hip: UTile::STAGE_OUT; the KAT above only reaches the split-chunk, direct-store path).
+    Windows at the start, around tile seams and at the ragged end against the restatement on the same bf16 operands (model.py:88-94)."""
+    spec = [s for s in conv_specs(V1) if s.key == f"generator/~/ups_{i}"][0]
+    n1 = 256 if i == 2 else 512  # frames per tile (UT2 / UT3)
+    B, L = 2, 300 * n1 + 77      # 602 tiles, a partial last tile
+    rng = np.random.default_rng(90 + i)
+    x = (rng.standard_normal((B, L, spec.cin)).astype(np.float32) * 2.0)
+    w, b = v1_params[spec.key]["w"], v1_params[spec.key]["b"]
+    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 1.0).cpu().numpy()
+    assert y.shape == (B, L * spec.stride, spec.cout)
+    s_ = spec.stride
+    for a, e in ((0, 700), (n1 - 40, n1 + 40), (150 * n1 - 300, 150 * n1 + 300), (L - 700, L)):
+        lo, hi = max(a - 2, 0), min(e + 2, L)
+        ref = orc.conv1d_transpose(bf(x[:, lo:hi]), bf(w), b.astype(np.float64), s_)
+        # a frame reads its two neighbours: frames a .. e - 1 have theirs inside the slice (or, at the tensor's own ends, the same zero padding)
+        got = y[:, a * s_ : e * s_]
+        want = ref[:, (a - lo) * s_ : (e - lo) * s_]
+        assert np.abs(got - want).max() <= 2.0 ** -8 * np.abs(ref).max(), (i, a, e)
+
+
 def test_conv_pre_and_post_bf16(gen, v1_params, dev):
     mel = synthetic_mel(2, 300, 5)
     w, b = v1_params["generator/~/conv1_d"]["w"], v1_params["generator/~/conv1_d"]["b"]
