@@ -462,6 +462,9 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / PEAK_TFLOPS[args.dtype],
                 "traffic": traffic,  # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc passes) or null
+                # calibration, not the contract's peak: a pure MFMA stream (operands in registers, no LDS / memory traffic) sustains 1750 TF/s on pseudo-random
+                # bf16 operands and 2460 on constant ones on this chip's power budget (profiles/r03_e_mfma_peak.txt, tools/kbench/coissue 400 3)
+                "peak_sustained_mfma_only_random_operands": 1750.0 if args.dtype == "bf16" else None,
                 "traffic_algorithmic": 2.0 * B * (T * 64) * 128 * 2 if prof["kernel"].startswith("resblock_pair_g_bf16_k<GTile<128, 11") else None,
                 "mfma_util": util,
                 "counters_unavailable": why_not,

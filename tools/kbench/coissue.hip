@@ -294,6 +294,39 @@ __global__ __launch_bounds__(512) void filler_k(Rec* out, float* sink, int both,
         out[blockIdx.x * 8 + wave] = r;
     }
 }
+// the chip's SUSTAINED bf16 MFMA rate (power-limited clock) as a function of the operand data: every SIMD runs two waves of back-to-back
+// v_mfma_f32_32x32x16_bf16 on 8 accumulators; operands zero / one constant / pseudo-random per lane, refreshed from a small register pool
+__global__ __launch_bounds__(512) void mfma_peak_k(float* sink, int iters, int data_mode, unsigned seed) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    bf16x8 a[4], b[4];
+    unsigned h = (threadIdx.x + blockIdx.x * 512u) * 2654435761u + seed;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h = h * 1664525u + 1013904223u;
+            const float ra = ((int)(h >> 8) % 2001 - 1000) * 1e-3f;
+            h = h * 1664525u + 1013904223u;
+            const float rb = ((int)(h >> 8) % 2001 - 1000) * 1e-3f;
+            a[q][e] = (__bf16)(data_mode == 0 ? 0.f : data_mode == 1 ? 0.5f : ra);
+            b[q][e] = (__bf16)(data_mode == 0 ? 0.f : data_mode == 1 ? 0.25f : rb);
+        }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a[q]), "v"(b[(q + j) & 3]));
+    }
+    float sres = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sres += acc[j][0] + acc[j][7];
+    if (sres == 123.456f) *sink = sres;
+}
+
 typedef void (*fill_t)(Rec*, float*, int, int);
 
 typedef void (*kern_t)(Rec*, float*, int, int, int, int, int, const float*);
@@ -349,6 +382,31 @@ int main(int argc, char** argv) {
     for (auto& v : vs) {
         run(v, 0, 0, 0, iters_a, 0, ca, cb, ss);
         printf("  A alone, %-12s : %.3f ticks / MFMA (x%.3f)\n", v.name, ca / (iters_a * 8.0), ca / (iters_a * 8.0) / a_alone);
+    }
+    if (argc > 2 && atoi(argv[2]) == 3) {  // sustained MFMA rate vs operand data
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const char* names[] = {"all-zero operands", "one constant per operand", "pseudo-random operands in [-1, 1]"};
+        const int iters = 20000;  // x 32 MFMAs per wave
+        printf("sustained v_mfma_f32_32x32x16_bf16 rate, 256 workgroups x 8 waves (2 per SIMD), %d MFMAs per wave, three runs each:\n", iters * 32);
+        for (int dm = 0; dm < 3; ++dm) {
+            printf("  %-36s", names[dm]);
+            for (int rep = 0; rep < 3; ++rep) {
+                hipLaunchKernelGGL(mfma_peak_k, dim3(nwg), dim3(512), 0, 0, sink, rep == 0 ? 2000 : iters, dm, 12345u + rep);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, 0));
+                hipLaunchKernelGGL(mfma_peak_k, dim3(nwg), dim3(512), 0, 0, sink, iters, dm, 777u + rep);
+                CK(hipEventRecord(e1, 0));
+                CK(hipEventSynchronize(e1));
+                float ms;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                const double fl = (double)nwg * 8 * iters * 32.0 * 32768.0;
+                printf("  %7.1f TF/s (%.2f of 2500; %.2f ms)", fl / ms * 1e-9, fl / ms * 1e-9 / 2500.0, ms);
+            }
+            printf("\n");
+        }
+        return 0;
     }
     if (argc > 2 && atoi(argv[2]) == 2) {  // intra-wave fillers
         struct FV { const char* name; fill_t k; };
