@@ -259,7 +259,20 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             }
         }
     };
-    auto conv_phase_wreg = [&](const unsigned char* __restrict__ tile, int dl) {
+    // (the accumulators of a WREG pass start from the bias block as the first MFMA's C operand: 16 registers read from the LDS copy per
+    //  m-block instead of 16 * NR v_mov per convolution and wave)
+    auto conv_phase_wreg = [&](const unsigned char* __restrict__ tile, int dl, int conv) {
+        f32x16 bblk[MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 bv = *reinterpret_cast<const float4*>(sbias + conv * C + cb0 + 32 * mr + 8 * rq + 4 * lh);
+                bblk[mr][4 * rq + 0] = bv.x;
+                bblk[mr][4 * rq + 1] = bv.y;
+                bblk[mr][4 * rq + 2] = bv.z;
+                bblk[mr][4 * rq + 3] = bv.w;
+            }
         bf16x8 bf[2][NR];
         auto load_b = [&](int q, int par) {
             const int tap = q / KSTEPS, ks = q % KSTEPS;
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr)
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q < NQW ? q : 0][mr], bf[q & 1][nr], acc[mr][nr], 0, 0, 0);
+                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q < NQW ? q : 0][mr], bf[q & 1][nr], q == 0 ? bblk[mr] : acc[mr][nr], 0, 0, 0);
             for (int i = 0; i < MR * NR; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (q + 1 < NQT && i < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -289,10 +302,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         for (int q = 0; q < PA; ++q) load_a(q, q % RA);  // the stream's first fragments, under the tile staging
     }
     // this lane's 16 values of block nr -> tile rows (8 consecutive channels per lane after the swap), masked outside [0, L)
+    const bool interior = tw >= 0 && tw + W <= L;  // every row of the window lies inside the utterance: no zero-padding masks (wave-uniform)
     auto write_tile = [&](unsigned char* tile, int mr, int nr, unsigned p0, unsigned p1, unsigned q0, unsigned q1, int p) {
         const int row = GUARD + col0 + nr * 32;
         const int t = tw + col0 + nr * 32;
-        if (t < 0 || t >= L) p0 = p1 = q0 = q1 = 0u;
+        if (!interior && (t < 0 || t >= L)) p0 = p1 = q0 = q1 = 0u;
         swap_pair(p0, q0);
         swap_pair(p1, q1);
         const int slot = ((cb0 + 32 * mr) >> 3) + 2 * p + lh;
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     };
 
     __syncthreads();  // tile A staged, biases in LDS
-    init_acc(0);
+    if constexpr (!T::WREG) init_acc(0);
 
     constexpr int S2 = NQT % 4;  // ring slot at which a c2 phase starts
 #pragma nounroll
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         const int dl = pr == 0 ? d0 : (pr == 1 ? d1 : d2);
         // ---- c1 over A ----
         if constexpr (T::WREG) {
-            conv_phase_wreg(tA, dl);
+            conv_phase_wreg(tA, dl, 2 * pr);
             load_w_all(2 * pr + 1);  // c2's fragments, in flight under the epilogue
         } else {
             conv_phase(2 * pr, std::integral_constant<int, 0>{}, tA, dl);
@@ -325,11 +339,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     write_tile(tT, mr, nr, lrelu01_pack(c[r0 + 0], c[r0 + 1]), lrelu01_pack(c[r0 + 2], c[r0 + 3]),
                                lrelu01_pack(c[r0 + 4], c[r0 + 5]), lrelu01_pack(c[r0 + 6], c[r0 + 7]), p);
                 }
-        init_acc(2 * pr + 1);
+        if constexpr (!T::WREG) init_acc(2 * pr + 1);
         __syncthreads();  // T written; every wave is done reading A
         // ---- c2 over T (rate 1) ----
         if constexpr (T::WREG) {
-            conv_phase_wreg(tT, 1);
+            conv_phase_wreg(tT, 1, 2 * pr + 1);
             load_w_all(2 * pr + 2);  // the next pair's c1 (nothing after the last pair)
         } else {
             conv_phase(2 * pr + 1, std::integral_constant<int, S2>{}, tT, 1);
@@ -366,9 +380,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                         r.z = pack_bf16x2(c[r0 + 4], c[r0 + 5]);
                         r.w = pack_bf16x2(c[r0 + 6], c[r0 + 7]);
                         xr[mr][nr][p] = r;
-                        write_tile(tA, mr, nr, act2(r.x), act2(r.y), act2(r.z), act2(r.w), p);
+                        write_tile(tA, mr, nr, act2(r.x), act2(r.y), act2(r.z), act2(r.w), p);  // lrelu of the ROUNDED x', as the pair path's staging does
                     }
-            init_acc(2 * pr + 2);
+            if constexpr (!T::WREG) init_acc(2 * pr + 2);
             __syncthreads();  // A written; every wave is done reading T
         }
     }
