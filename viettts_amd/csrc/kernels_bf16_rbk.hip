@@ -455,7 +455,11 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #define VTTS_RB64_WG 2
 #endif
 //                                     C   KS   W  WM WN PA MINWG
-template <int KS> using RB32 = RBTile<32, KS, VTTS_RB32_W, 1, VTTS_RB32_WN, 3, VTTS_RB32_WG>;
+#ifndef VTTS_RB32K3_W  // k = 3 at C = 32: 256-step windows, three workgroups per CU (1.17 -> 1.03 ms per launch: its phases are 768 cycles of MFMA each, more
+#define VTTS_RB32K3_W 256   // waves in flight hide their start-up latencies; k = 7 loses 15 % that way, gpurun_out/r03_exp24)
+#define VTTS_RB32K3_WG 3
+#endif
+template <int KS> using RB32 = RBTile<32, KS, KS == 3 ? VTTS_RB32K3_W : VTTS_RB32_W, 1, VTTS_RB32_WN, 3, KS == 3 ? VTTS_RB32K3_WG : VTTS_RB32_WG>;
 template <int KS> using RB64 = RBTile<64, KS, VTTS_RB64_W, 1, VTTS_RB64_WN, 3, VTTS_RB64_WG>;
 template <int KS> using RB128 = RBTile<128, KS, 128, 2, 2, 3, 2>;
 constexpr bool RB64_ALL_K = RB64<11>::LDS_BYTES * VTTS_RB64_WG <= 160 * 1024 && VTTS_RB64_W - 2 * 60 >= 128;  // k = 7, 11 too once the window is wide enough
