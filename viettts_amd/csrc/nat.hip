@@ -635,19 +635,36 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
         }
         if (half > 1) __syncthreads();
     }
-    if (kw > 0) return;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (!live[nt]) continue;
+    // The cell update (3 sigmoids + 2 tanh per (unit, sentence): ~1000 VALU instructions per lane for a wave's 8 pairs) is shared out: wave 0
+    // hands the gate sums to the workgroup through LDS and wave w takes the (sentence tile, unit pair) blocks w, w + KW, ...  Round 2 left it to
+    // wave 0 alone while the other seven idled: ~2.5 us of every 22 us step.  The same operations on the same values: the same bits.
+    auto cell_update = [&](int nt, int rq, float gi, float gg, float gf, float go) {
+        if (!live[nt]) return;
         const int b = b0 + 32 * nt + l31;
+        const int u = 8 * slice + 2 * rq + lh;
+        float c = cst[(size_t)u * Bp + b];
+        c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
+        cst[(size_t)u * Bp + b] = c;
+        hout[nat_zidx(u, b, Bp)] = sigmoidf_(go) * tanhf(c);
+    };
+    if constexpr (KW == 1) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int u = 8 * slice + 2 * rq + lh;
-            const float gi = acc[nt][0][4 * rq + 0], gg = acc[nt][0][4 * rq + 1], gf = acc[nt][0][4 * rq + 2], go = acc[nt][0][4 * rq + 3];
-            float c = cst[(size_t)u * Bp + b];
-            c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
-            cst[(size_t)u * Bp + b] = c;
-            hout[nat_zidx(u, b, Bp)] = sigmoidf_(go) * tanhf(c);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) cell_update(nt, rq, acc[nt][0][4 * rq + 0], acc[nt][0][4 * rq + 1], acc[nt][0][4 * rq + 2], acc[nt][0][4 * rq + 3]);
+    } else {
+        if (kw == 0) {  // (it was the only reader of red[0] at the tree's last level, and nothing else writes it now)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[0][nt][r][lane] = acc[nt][0][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int blk = 0; blk < NT * 4; ++blk) {
+            if (blk % KW != kw) continue;  // wave-uniform
+            const int nt = blk / 4, rq = blk % 4;
+            cell_update(nt, rq, red[0][nt][4 * rq + 0][lane], red[0][nt][4 * rq + 1][lane], red[0][nt][4 * rq + 2][lane], red[0][nt][4 * rq + 3][lane]);
         }
     }
 }
