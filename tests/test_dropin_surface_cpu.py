@@ -3,8 +3,11 @@ NTT123/vietTTS switches packages, not call sites.  Signatures are checked agains
 (vietTTS/hifigan/mel2wave.py:20, vietTTS/nat/text2mel.py:22,37,61,85-87, vietTTS/synthesizer.py:12-18)."""
 import importlib
 import inspect
+import pathlib
 
 import pytest
+
+REPO = pathlib.Path(__file__).resolve().parent.parent
 
 
 def test_reference_module_paths_resolve():
@@ -46,3 +49,19 @@ def test_missing_checkpoints_raise_like_the_reference(tmp_path, monkeypatch):
     t2m.set_duration_model(None)
     with pytest.raises((FileNotFoundError, OSError)):
         t2m_ref.predict_duration([1, 2, 3])
+
+
+def test_committed_counters_belong_to_the_sources_in_the_tree():
+    """bench.py reports roofline.traffic / roofline.mfma_util from profiles/counters_<dtype>.json only while the digest recorded there equals the
+    digest of the kernel sources (tools/profile_final.sh writes it): a kernel change without a fresh profile run would silently drop them from the
+    bench line — fail here instead, where it is cheap to notice."""
+    import json
+
+    from viettts_amd.csrc.build import _digest
+
+    for dt in ("bf16", "f32"):
+        rec = json.load(open(REPO / "profiles" / f"counters_{dt}.json"))
+        assert rec["source_digest"] == _digest(), f"profiles/counters_{dt}.json is from another build: re-run tools/profile_final.sh (tools/r03_verify.sh) and copy the set"
+        assert rec["time_weighted_mfma_util_resblock_kernels"] and len(rec["kernels"]) > 10
+        tag = rec["tag"]
+        assert (REPO / "profiles" / f"{tag}_pmc.md").exists() and (REPO / "profiles" / f"{tag}_kernel_stats.md").exists()
