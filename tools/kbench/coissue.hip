@@ -408,6 +408,29 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 2 && atoi(argv[2]) == 4) {  // a sustained MFMA-only load for power / clock sampling: coissue <iters> 4 <data mode 0|1|2> <seconds>
+        const int dm = argc > 3 ? atoi(argv[3]) : 2;
+        const double secs = argc > 4 ? atof(argv[4]) : 8.0;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        const int iters = 20000;
+        double total_ms = 0.0;
+        int n = 0;
+        while (total_ms < secs * 1e3) {
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < 8; ++r) hipLaunchKernelGGL(mfma_peak_k, dim3(nwg), dim3(512), 0, 0, sink, iters, dm, 777u + n * 8 + r);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+            n += 8;
+        }
+        const double fl = (double)nwg * 8 * iters * 32.0 * 32768.0 * n;
+        printf("MFMA-only load, data mode %d: %d launches in %.2f s = %.1f TF/s (%.2f of 2500)\n", dm, n, total_ms * 1e-3, fl / total_ms * 1e-9, fl / total_ms * 1e-9 / 2500.0);
+        return 0;
+    }
     if (argc > 2 && atoi(argv[2]) == 2) {  // intra-wave fillers
         struct FV { const char* name; fill_t k; };
         const FV fv[] = {{"0", filler_k<0, 0>}, {"2", filler_k<2, 0>}, {"4", filler_k<4, 0>}, {"6", filler_k<6, 0>}, {"8", filler_k<8, 0>}, {"12", filler_k<12, 0>},
