@@ -48,7 +48,8 @@ typedef enum vtts_dtype {
  * The architecture-defining fields Generator.__init__ reads from the JSON config
  * (vietTTS/hifigan/model.py:81-106; assets/hifigan/config.json:2,11-15,19).
  * resblock: 1 = ResBlock1 (model.py:13-51; three dilations per kernel size; every engine), 2 = ResBlock2 (model.py:54-74;
- * two dilations per kernel size, the third entry is ignored; VTTS_F32 handles only).  0 is read as 1.
+ * two dilations per kernel size, the third entry is ignored; every engine — VTTS_BF16 for the V1 channel / kernel-size shapes its
+ * kernels cover, as for ResBlock1, on the per-convolution kernel).  0 is read as 1.
  */
 typedef struct vtts_hifigan_cfg {
     int32_t num_mels;                                        /* 80  */

@@ -517,3 +517,46 @@ def test_bf16_edge_lengths_vs_oracle(gen, dev, edge_oracle, capsys, fuse, tiles)
         gen.set_option("tiles", 0)
     with capsys.disabled():
         print(f"\n[bf16 edge lengths vs fp64 oracle, fuse={fuse} tiles={tiles}] worst max|dy| {worst[0]:.2e}, worst SNR {worst[1]:.1f} dB")
+
+
+def test_resblock2_generator_bf16_vs_oracle(dev, capsys):
+    """ResBlock2 generators (vietTTS/hifigan/model.py:54-74, config "resblock": "2", model.py:84) of the V1 shapes on the bf16 engine: two
+    residual convolutions per block (x = c(leaky_relu(x)) + x, rates (1, 3)) on the per-convolution kernel, the MRF mean and the next
+    layer's LeakyReLU in the last epilogue.  Against the fp64 oracle with the bf16 bounds of the ResBlock1 tests; rows of a batch and
+    rows of a ragged batch against the utterance alone (bit-identical)."""
+    import dataclasses
+
+    from viettts_amd.hifigan.generator import Generator
+
+    cfg = dataclasses.replace(V1, resblock="2", resblock_dilation_sizes=((1, 3), (1, 3), (1, 3)))
+    cfg.validate()
+    params = synthetic_params(cfg, 4321, "scaled")
+    assert "generator/~/res_block1_0/~/conv1_d_1" in params and "generator/~/res_block1_0/~/convs1_0" not in params
+    g = Generator(cfg, device=dev, dtype="bf16")
+    g.load_params(params)
+    try:
+        outs = {}
+        for T in (3, 13):
+            mel = synthetic_mel(1, T, 500 + T)
+            want_y, want_pre = orc.generator_forward(params, mel, cfg, np.float64, return_pre_tanh=True)
+            wav, pre = g.forward_tap(torch.from_numpy(mel).to(dev), "pre_tanh")
+            torch.cuda.synchronize()
+            e_y, snr = _edge_check(wav.cpu().numpy()[0], pre.cpu().numpy()[0], want_y[0, :, 0], want_pre[0, :, 0], ("resblock2", T))
+            outs[T] = (mel, wav.clone())
+            with capsys.disabled():
+                print(f"\n[bf16 ResBlock2 generator vs fp64 oracle, T={T}] max|dy| {e_y:.2e}, pre-tanh SNR {snr:.1f} dB")
+        g.set_option("fuse", 0)  # the upsamplers / conv_pre on the first-generation kernel too (another summation order: bounds, not bits)
+        wav0, pre0 = g.forward_tap(torch.from_numpy(outs[13][0]).to(dev), "pre_tanh")
+        g.set_option("fuse", 2)
+        want_y, want_pre = orc.generator_forward(params, outs[13][0], cfg, np.float64, return_pre_tanh=True)
+        _edge_check(wav0.cpu().numpy()[0], pre0.cpu().numpy()[0], want_y[0, :, 0], want_pre[0, :, 0], ("resblock2 fuse=0", 13))
+        batch = np.full((2, 13, cfg.num_mels), 55.0, np.float32)
+        batch[0] = outs[13][0][0]
+        batch[1, :3] = outs[3][0][0]
+        got = g.forward_ragged(torch.from_numpy(batch).to(dev), [13, 3])
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], outs[13][1][0]) and torch.equal(got[1, : 256 * 3], outs[3][1][0]) and not got[1, 256 * 3 :].any()
+        both = g(torch.from_numpy(np.concatenate([outs[13][0], outs[13][0]])).to(dev))
+        assert torch.equal(both[0], outs[13][1][0]) and torch.equal(both[1], outs[13][1][0])
+    finally:
+        g.close()

@@ -211,8 +211,8 @@ def test_resblock2_generator_vs_reference_golden(golden_dir, dev):
     want = orc.generator_forward(params, g["mel"], TINY2, np.float64)[..., 0]
     assert np.abs(wav.cpu().numpy() - want).max() < 2e-5
     gen.close()
-    with pytest.raises(_lib.VttsError):  # the bf16 kernels are fused ResBlock1 pairs
-        Generator(TINY2, device=dev, dtype="bf16")
+    with pytest.raises(_lib.VttsError):  # the bf16 kernels cover the V1 channel / kernel-size / rate shapes only (ResBlock2 of those
+        Generator(TINY2, device=dev, dtype="bf16")  # shapes: tests/test_gpu_bf16.py::test_resblock2_generator_bf16_vs_oracle)
 
 
 def test_parallel_resblocks_schedule_is_bit_identical(dev):

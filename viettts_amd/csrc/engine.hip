@@ -201,7 +201,8 @@ int build_layers_bf16(vtts_hifigan* h) {
             }
         }
     }
-    for (size_t r = 0; r < h->idx_res.size(); ++r) {
+    // (ResBlock2 generators, model.py:54-74, have no fused packings: their two convolutions per block run on the per-convolution kernel)
+    for (size_t r = 0; r < h->idx_res.size() && h->cfg.resblock != 2; ++r) {
         for (int z = 0; z < 3; ++z) {
             Layer& c1 = h->layers[h->idx_res[r] + 2 * z];
             const Layer& c2 = h->layers[h->idx_res[r] + 2 * z + 1];
@@ -214,7 +215,7 @@ int build_layers_bf16(vtts_hifigan* h) {
             off = align_up(off + (size_t)2 * c1.cin * sizeof(float), 256);
         }
     }
-    for (size_t r = 0; r < h->idx_res.size(); ++r) {
+    for (size_t r = 0; r < h->idx_res.size() && h->cfg.resblock != 2; ++r) {
         Layer& c0 = h->layers[h->idx_res[r]];
         const int dils[3] = {h->layers[h->idx_res[r] + 0].dil, h->layers[h->idx_res[r] + 2].dil, h->layers[h->idx_res[r] + 4].dil};
         bool ok = resblock_bf16_supported(c0.cin, c0.k, dils);
@@ -714,6 +715,14 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 const char* cur = bufX;
                 const bool last_rb = (j == nk - 1);
                 int rcc;
+                if (c.resblock == 2) {
+                    // ResBlock2: x = c_z(leaky_relu(x, 0.1)) + x, z = 0, 1 (model.py:69-74): the running x is stored raw (it is the residual) and
+                    // activated on load; the MRF sum / mean and the consumer's LeakyReLU in the second convolution's epilogue.  X -> C -> S
+                    if ((rcc = run_layer_bf16(h, h->layers[base], cur, C, C, nb, (int)L, 0.1f, 1.0f, cur, tC, 0, 1.f, cs))) return rcc;
+                    if ((rcc = before_last())) return rcc;
+                    return run_layer_bf16(h, h->layers[base + 1], tC, C, C, nb, (int)L, 0.1f, last_rb ? next_slope : 1.0f, tC, bufS, j > 0 ? 1 : 0,
+                                          last_rb ? (float)nk : 1.0f, cs);
+                }
                 // the whole-ResBlock kernel where it exists and is the faster choice (fuse = 3: wherever it exists)
                 if (h->opt_fuse >= 2 && h->layers[base].has_rb && (h->opt_fuse >= 3 || resblock_bf16_preferred(h->layers[base].cin, h->layers[base].k))) {
                     // the whole ResBlock in one kernel: X -> S (store / accumulate / accumulate-and-divide)
@@ -976,8 +985,6 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
     }
     if (cfg->resblock != 0 && cfg->resblock != 1 && cfg->resblock != 2)
         return fail(VTTS_ERR_INVALID, "resblock must be 1 (ResBlock1) or 2 (ResBlock2), got %d", cfg->resblock);
-    if (cfg->resblock == 2 && dtype != VTTS_F32)
-        return fail(VTTS_ERR_INVALID, "ResBlock2 generators run on the fp32 engine (the bf16 kernels are fused ResBlock1 pairs)");
     if (device < 0) return fail(VTTS_ERR_INVALID, "device %d out of range", device);
     // the device itself is first touched in pack()/bind_packed(): planning needs no GPU
     auto* h = new (std::nothrow) vtts_hifigan();
