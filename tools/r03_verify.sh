@@ -3,6 +3,6 @@
 O=gpurun_out/r03_verify; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
-bash tools/profile_final.sh r03_e > $O/profile_final.log 2>&1; tail -3 $O/profile_final.log
-cp gpurun_out/r03_e/counters_bf16.json gpurun_out/r03_e/counters_f32.json profiles/ 2>/dev/null
+bash tools/profile_final.sh r03_g > $O/profile_final.log 2>&1; tail -3 $O/profile_final.log
+cp gpurun_out/r03_g/counters_bf16.json gpurun_out/r03_g/counters_f32.json profiles/ 2>/dev/null
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-600 $O/bench.json; tail -2 $O/bench.err
