@@ -28,6 +28,11 @@
 // launch, profiles/r02_a_pair_kernel_findings.md).  The same treatment of the staging loads and of epilogue 2's row accesses
 // (buffer loads / stores with SGPR row offsets, -200 VALU per tile) measured no faster.  A persistent, software-pipelined
 // one-workgroup-per-CU variant (tools/kbench/experiments/kernels_bf16_rbp.hip) is correct and 15 % SLOWER: see the same file.
+// Round 3 (profiles/r03_a_coissue_findings.md, r03_c_narrow_stage_findings.md): 16-row blocked LDS tiles at C = 32 / 64, register-resident
+// weights and LDS-resident raw residual rows at C = 32, the MRF mean as a reciprocal multiply, no packed-f32 VALU.  Built, bit-correct and
+// measured no faster, then removed again (the code is in the history up to commit a56dd21): the residual / MRF rows added by the matrix
+// cores through identity A fragments (VTTS_RES_MFMA), an MFMA stream paced by s_nop (VTTS_PACE_NOP), column-half software pipelining of
+// the epilogues, conv_post fused into the last pair launch.
 #include <stdio.h>
 #include <string.h>
 
@@ -38,18 +43,12 @@
 #ifndef VTTS_XCD_MAP  // XCD-aware tile order (A/B switch, tools/kbench): see resblock_pair_g_bf16_k
 #define VTTS_XCD_MAP 1
 #endif
-#ifndef VTTS_RES_MFMA  // residual / MRF rows added by the matrix cores (identity A fragments) instead of unpack + v_add: A/B switch, tools/kbench.
-#define VTTS_RES_MFMA 0  // Correct and bit-stable, but NOT faster (round 3, profiles/r03_a_coissue_findings.md): -290 VALU per tile buy nothing
-#endif                   // because the requests that feed it are VMEM, which an MFMA stream on the same SIMD blocks just as it blocks the adds' loads
 
 #ifndef VTTS_RAWRES  // C = 32: the tile's raw rows kept in LDS as the residual (A/B switch)
 #define VTTS_RAWRES 1
 #endif
 #ifndef VTTS_WREG  // C = 32: the convolution's weights register-resident for the whole phase (A/B switch, tools/kbench)
 #define VTTS_WREG 1
-#endif
-#ifndef VTTS_PACE_NOP  // kernel-development switch (tools/kbench): s_nop <n> after every MFMA of the main loops (-1 = none)
-#define VTTS_PACE_NOP -1
 #endif
 #ifndef VTTS_LEAN  // lean loop addressing (buffer loads with SGPR offsets, per-tap swizzle terms): A/B switch, tools/kbench
 #define VTTS_LEAN 1
@@ -384,33 +383,6 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 const int tapn = tap + 1 < KS ? tap + 1 : KS - 1;
                 tap_terms(wrap ? tapn : tap, tn, xn);
                 const int ksn = wrap ? 0 : ksb + UB;
-#if VTTS_PACE_NOP >= 0
-                // kernel-development variant (tools/kbench): every MFMA followed by s_nop <n> and ONE look-ahead load, order pinned by
-                // sched_barrier — does a paced MFMA stream leave the co-resident workgroup's VALU phases more issue slots?
-#pragma unroll
-                for (int i = 0; i < UB; ++i) {
-                    const int sa = s0 + i + PA, sc = sa < NSTEPS ? sa : NSTEPS - 1;
-                    const int tapa = sc / NKS, ksa = sc - tapa * NKS;
-                    const int soff = ((tapa * KSTEPS + ks0 + ksa) * MB) * 1024;
-                    static_assert(SPRB >= 16, "the paced experiment addresses row-major tiles only");
-                    const unsigned baddr = (i + 1 < UB) ? ta + (xs ^ (unsigned)((ksb + i + 1) << 5)) : tn + (xn ^ (unsigned)(ksn << 5));
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int m = 0; m < MR * NR; ++m) {
-                        const int mr = m / NR, nr = m % NR;
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % RA][mr], bf[i & 1][nr],
-                                                                              (decltype(first_tag)::value && i == 0) ? bblk[mr] : acc[mr][nr], 0, 0, 0);
-                        asm volatile("s_nop %0" ::"n"(VTTS_PACE_NOP));
-                        if (m < MR) {
-                            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + m * 1024, soff, 0);
-                            af[(i + PA) % RA][m] = __builtin_bit_cast(bf16x8, v);
-                        } else if (m - MR < NR) {
-                            bf[(i + 1) & 1][m - MR] = *reinterpret_cast<const bf16x8*>(xt + baddr + (m - MR) * 32 * PB);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-#else
 #pragma unroll
                 for (int i = 0; i < UB; ++i) {
                     load_a2(s0 + i + PA, (i + PA) % RA);
@@ -419,7 +391,6 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     mfma_step(i % RA, i & 1, decltype(first_tag)::value && i == 0);
                     pin_step(true);
                 }
-#endif
             };
 #else
             auto block = [&](int s0, auto first_tag) {  // the first block of a fresh pass is peeled: its first step reads the bias block
@@ -493,36 +464,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         qd = r[1];
     };
 
-#if VTTS_RES_MFMA
-    // The residual `x = xt + x` (model.py:50) and the MRF accumulate `xs += rb(x)` (model.py:118-120) on the matrix cores: rows of a
-    // [B][L][C] tensor, loaded 16 bytes per lane as (time l31, channels 16p + 8lh ..) of this wave's m-block, ARE the B fragment of
-    // a k-step whose A fragment is the identity block (row m <-> channel 16p + k), so  acc += I_p * rows  is one MFMA per 8 values
-    // where the vector path needs 2 v_permlane32_swap + 8 unpacks + 8 v_add on the issue port the co-resident workgroup's MFMAs
-    // need (profiles/r01_j_kbench_findings.md: ~290 of a tile's ~1400 VALU instructions per wave, twice that on a chain's third
-    // launch).  Products by 1.0 and sums with 15 zeros are exact: the value is the fp32 sum acc + x, rounded once, as before.
-    // The residual rows are requested one per unit of epilogue 1 (whose accumulator registers die unit by unit), land under
-    // it, and open phase 2:  acc2 = (b2 + x) + c2(xt)  instead of  (b2 + c2(xt)) + x.
-    uint4 rv[MR][2][NR];
-    auto res_row = [&](const unsigned short* __restrict__ src, int mr, int p, int nr) {
-        const int t = t0 + wn * (N1 / WN) + nr * 32 + l31;
-        const int tc = t < L ? t : L - 1;  // rows past the end are never stored: any in-bounds address will do
-        return *reinterpret_cast<const uint4*>(src + (size_t)tc * C + wm * (C / T::WM) + mr * 32 + 16 * p + 8 * lh);
-    };
-    auto ident_frag = [&](int p) {  // A fragment of I_p: lane (m = l31, k-group lh) holds k = 8lh .. 8lh+7; 1.0 where m == 16p + k
-        const int j = l31 - 16 * p - 8 * lh;
-        uint4 f;
-        f.x = j == 0 ? 0x3f80u : (j == 1 ? 0x3f800000u : 0u);
-        f.y = j == 2 ? 0x3f80u : (j == 3 ? 0x3f800000u : 0u);
-        f.z = j == 4 ? 0x3f80u : (j == 5 ? 0x3f800000u : 0u);
-        f.w = j == 6 ? 0x3f80u : (j == 7 ? 0x3f800000u : 0u);
-        return __builtin_bit_cast(bf16x8, f);
-    };
-#endif
 
     // ---------------- epilogue 1: LeakyReLU(0.1), bf16, zero outside [0, L) -> xt tile in LDS ----------------
-#if !VTTS_RES_MFMA
     load_bias(a.bias + C);  // c2's bias: lands while epilogue 1 runs
-#endif
     {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
@@ -544,15 +488,9 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     swap_pair(p1, q1);
                     const int slot = (cb >> 3) + lh;
                     *reinterpret_cast<uint4*>(xt + tile_off<SPR2>(row, slot)) = make_uint4(p0, p1, q0, q1);
-#if VTTS_RES_MFMA
-                    rv[mr][p][nr] = res_row(xg, mr, p, nr);  // into the registers this unit's accumulators just left
-#endif
                 }
             }
         }
-#if VTTS_RES_MFMA
-        load_bias(a.bias + C);  // c2's bias, once epilogue 1's accumulators are dead (the residual rows took their registers): lands under the barrier
-#endif
         // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
         for (int u = tid; u < 2 * H2 * SPR2; u += THREADS) {
             const int row = N1 + u % (2 * H2), c = u / (2 * H2);  // consecutive lanes: consecutive rows of one slot (conflict-free in the blocked tiles)
@@ -563,24 +501,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     VTTS_TL(a, wg_lin, 3);
 
     // ---------------- phase 2: c2 over the xt tile (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
-#if VTTS_RES_MFMA
-    {
-        const bf16x8 id0 = ident_frag(0), id1 = ident_frag(1);
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id0, __builtin_bit_cast(bf16x8, rv[mr][0][nr]), bblk[mr], 0, 0, 0);
-                acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id1, __builtin_bit_cast(bf16x8, rv[mr][1][nr]), acc[mr][nr], 0, 0, 0);
-            }
-    }
-    conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::false_type{});
-#else
     if constexpr (T::WREG)
         conv_phase_wreg(1, std::integral_constant<int, SPR2>{});
     else
         conv_phase(static_cast<const unsigned char*>(a.wp) + T::CONV_BYTES, 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0, std::true_type{});
-#endif
     VTTS_TL(a, wg_lin, 4);
 
     // ---------------- epilogue 2: + x [MRF accumulate / mean] [consumer's LeakyReLU] -> bf16, 16-byte stores ----------------
@@ -623,24 +547,6 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                         acc[mr][nr][r0 + 6] = vadd_raw(bf16_lo(r.w), acc[mr][nr][r0 + 6]); acc[mr][nr][r0 + 7] = vadd_raw(bf16_hi(r.w), acc[mr][nr][r0 + 7]);
                     }
         };
-#if VTTS_RES_MFMA
-        if (a.acc_add != 0) {                                               // xs += rb(x)       (model.py:118-120)
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) rv[mr][p][nr] = res_row(yg, mr, p, nr);
-            const bf16x8 id0 = ident_frag(0), id1 = ident_frag(1);
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                for (int nr = 0; nr < NR; ++nr) {
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id0, __builtin_bit_cast(bf16x8, rv[mr][0][nr]), acc[mr][nr], 0, 0, 0);
-                    acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(id1, __builtin_bit_cast(bf16x8, rv[mr][1][nr]), acc[mr][nr], 0, 0, 0);
-                }
-        }
-#else
         if constexpr (T::RAWRES) {                                          // x = xt + x        (model.py:50), rows from the LDS copy
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr)
@@ -662,7 +568,6 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
             add_rows(xg);                                                   // x = xt + x        (model.py:50)
         }
         if (a.acc_add != 0) add_rows(yg);                                   // xs += rb(x)       (model.py:118-120)
-#endif
         VTTS_TL(a, wg_lin, 12);
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
