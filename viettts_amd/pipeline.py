@@ -11,7 +11,7 @@ gives every utterance the zero padding it would see alone and skips the tiles pa
 """
 from __future__ import annotations
 
-from typing import Dict, Optional, Sequence
+from typing import List, Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -20,8 +20,33 @@ from .dist import shard_utterances
 from .nat import text2mel as t2m
 
 
+PASS_FRAMES = 65536  # mel frames per pass the generator's launches are sized for (engine.hip: pick_microbatch)
+
+
+def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: int = 0) -> List[List[int]]:
+    """Cut ``rows`` (sorted by ascending ``frames``) into the generator's ragged batches.  gen_batch > 0: at most that many sentences
+    per batch.  gen_batch = 0: as few passes as PASS_FRAMES of REAL frames each allow (the ragged kernels skip the tiles past an
+    utterance's end, so padding costs workspace, not time), the passes balanced by frames: 256 transcript sentences (54.7k frames,
+    longest 281) are ONE pass instead of four of 64 sentences — fewer, larger launches (generator stage 38.1 -> 34 ms)."""
+    rows = list(rows)
+    if not rows:
+        return []
+    if gen_batch > 0:
+        return [rows[i : i + gen_batch] for i in range(0, len(rows), gen_batch)]
+    total = int(sum(frames))
+    k = max(1, -(-total // int(PASS_FRAMES * 1.25)))
+    out, acc, cut = [[]], 0, 1
+    for r, f in zip(rows, frames):
+        if acc >= total * cut / k and cut < k and out[-1]:
+            out.append([])
+            cut += 1
+        out[-1].append(r)
+        acc += int(f)
+    return out
+
+
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
-                         dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 64,
+                         dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 0,
                          timing: Optional[dict] = None) -> Dict[int, np.ndarray]:
     """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index.  ``timing`` (a dict) receives
     device-synchronised wall seconds per stage."""
@@ -62,13 +87,18 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         # alone): sentences sorted by length, dealt into batches of at most `gen_batch`, cut to the batch's longest
         ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
         todo = sorted((r for r, k in enumerate(ok) if gfr[k] > 0), key=lambda r: gfr[ok[r]])
-        step = gen_batch if ragged else 1
         pending = []
-        for i0 in range(0, len(todo), step):
-            rows = todo[i0 : i0 + step]
+        for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1):
             fr = [gfr[ok[r]] for r in rows]
             batch = mel_dev[torch.tensor(rows, device=mel_dev.device), : max(fr)].contiguous()  # a device-side gather (plumbing)
-            w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
+            if ragged:
+                generator.set_option("microbatch", len(rows))  # one pass for the batch (the engine's own cut is PASS_FRAMES of PADDED frames)
+                try:
+                    w = generator.forward_ragged(batch, fr)
+                finally:
+                    generator.set_option("microbatch", 0)
+            else:
+                w = generator(batch)
             host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
             host.copy_(w, non_blocking=True)  # pinned, stream-ordered: the next batch computes behind this copy's enqueue
             pending.append((rows, fr, host))
