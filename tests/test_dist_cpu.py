@@ -103,6 +103,27 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_generator_batches_cover_every_sentence_once_and_balance_by_frames():
+    """viettts_amd/pipeline.py::_generator_batches — the ragged batches the pipeline hands the generator: every row exactly once, in
+    ascending-length order, as few passes as PASS_FRAMES of real frames allow, the passes balanced by frames; gen_batch > 0 caps the count."""
+    import random
+
+    from viettts_amd.pipeline import PASS_FRAMES, _generator_batches
+
+    rnd = random.Random(5)
+    for n in (1, 7, 256, 1024, 3000):
+        fr = sorted(rnd.randint(40, 300) for _ in range(n))
+        rows = list(range(100, 100 + n))
+        out = _generator_batches(rows, fr)
+        assert [r for b in out for r in b] == rows and all(out)
+        sums = [sum(fr[r - 100] for r in b) for b in out]
+        assert len(out) == max(1, -(-sum(fr) // int(PASS_FRAMES * 1.25)))
+        assert max(sums) <= PASS_FRAMES * 1.25 + 300 and (len(out) == 1 or max(sums) - min(sums) <= 2 * 300)
+        capped = _generator_batches(rows, fr, 64)
+        assert [r for b in capped for r in b] == rows and max(len(b) for b in capped) <= 64
+    assert _generator_batches([], []) == []
+
+
 def test_gloo_world2_broadcast_and_gather():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
