@@ -190,6 +190,8 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *               utterance 0.81 -> 0.69 ms bf16, 4.57 -> 3.65 ms fp32 together with "chains"); dropped when an option or the weight
  *               blob changes; inside a caller's own stream capture the launches are simply enqueued.  0 = always eager.
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
+ *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
+ *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.
  *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
  */
 int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value);

@@ -120,6 +120,8 @@ struct vtts_hifigan {
     std::vector<GraphEntry> graphs;  // at most GRAPH_SLOTS, least recently used evicted
     hipStream_t cap_stream = nullptr; // launches are recorded on this stream, graphs are launched on the caller's
     uint64_t epoch = 0, use_clock = 0;  // epoch: bumped by everything a captured launch sequence bakes in (options, the weight blob)
+    int64_t opt_zigzag = 1;          // consecutive launches walk the batch in alternating directions (see next_zrev)
+    unsigned zrev_count = 0;
     int64_t opt_chains = 1;          // small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other, 2 = always)
     hipEvent_t ev_chain[3] = {nullptr, nullptr, nullptr};  // bf16: ResBlock j's output is in the shared accumulator (orders the accumulating epilogues)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
@@ -345,6 +347,12 @@ struct Act {  // channel-major activation view
     long sb, sc, st;
 };
 
+// A launch's output (up to 1.07 GB at B = 64 x T = 1024) is the next launch's input, and the last 256 MB written are still in the Infinity
+// Cache when that launch starts: walking the batch (blockIdx.z) in the opposite direction makes the consumer start with them instead of
+// with the utterances written first, which have long been evicted (bf16 pass 40.00 -> 39.87 ms, three interleaved repetitions,
+// gpurun_out/r03_exp40; the fp32 MFMA kernels take the same flag).  The samples do not depend on the order: utterances are independent.
+int next_zrev(vtts_hifigan* h) { return h->opt_zigzag ? (int)(h->zrev_count++ & 1) : 0; }
+
 int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_in, const float* res, float* y,
               int acc_mode, float div, int tanh_out, float* pre_act, hipStream_t s) {
     ConvArgs a;
@@ -374,6 +382,7 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
     a.tanh_out = tanh_out;
     a.pre_act = pre_act;
     a.tile_pref = (int)h->opt_tiles;
+    a.zrev = next_zrev(h);
 
     hipError_t e;
     const bool ncw = x.st == 1 && x.sc == L && (x.sb % 4) == 0;
@@ -467,6 +476,7 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
     // conv_pre (80 -> 512, k = 7, fp32 mel in) runs on the same kernel since round 3 (7 taps per chunk, rows converted while staging)
     const bool ug = (l.kind == KIND_CONVT || l.bcls == BCLS_PRE) && l.has_ug && h->opt_fuse >= 1 && ug_pref && res == nullptr && acc_add == 0 && div == 1.0f;
     if (ug) a.wp = h->blob + l.off_ug;
+    if (ug) a.zrev = next_zrev(h);
     hipError_t e = ug ? launch_convt_g_bf16(l.bcls, a, s) : launch_conv_bf16(l.bcls, K, a, s);
     if (prof) {
         HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
@@ -497,6 +507,7 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     a.acc_add = acc_add;
     a.div = div;
     a.tile_pref = (int)h->opt_tiles;
+    a.zrev = next_zrev(h);
     const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
     if (prof) {
         if (h->prof_used == h->prof_events.size()) {
@@ -537,6 +548,7 @@ int run_resblock_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, in
     a.slope_out = slope_out;
     a.acc_add = acc_add;
     a.div = div;
+    a.zrev = next_zrev(h);
     hipError_t e = launch_resblock_bf16(rb[0].cin, rb[0].k, a, s);
     if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused ResBlock launch for %s failed: %s", rb[0].key.c_str(), hipGetErrorString(e));
     return VTTS_OK;
@@ -1417,6 +1429,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "graph")) {
         if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "graph must be 0 (always eager) or 1 (small launches replay a captured hipGraph)");
         h->opt_graph = value;
+    } else if (!strcmp(name, "zigzag")) {
+        if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "zigzag must be 0 or 1");
+        h->opt_zigzag = value;
     } else if (!strcmp(name, "chains")) {
         if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "chains must be 0 (ResBlocks of a stage one after the other), 1 (side by side on small fp32 launches) or 2 (... on every single-micro-batch launch)");
         h->opt_chains = value;
@@ -1438,6 +1453,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "profile")) *value = h->opt_profile;
     else if (!strcmp(name, "tiles")) *value = h->opt_tiles;
     else if (!strcmp(name, "streams")) *value = h->opt_streams;
+    else if (!strcmp(name, "zigzag")) *value = h->opt_zigzag;
     else if (!strcmp(name, "chains")) *value = h->opt_chains;
     else if (!strcmp(name, "graph")) *value = h->opt_graph;
     else if (!strcmp(name, "graphs_cached")) {

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int wn = wave % WN;
     const int l31 = lane & 31;
     const int lh = lane >> 5;
-    const int b = blockIdx.z;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int Lp = a.L;                                      // rows allocated per utterance
     const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid rows of this utterance, clamped to its slot (ragged batch: the rest reads as zero padding)
 #if VTTS_XCD_MAP

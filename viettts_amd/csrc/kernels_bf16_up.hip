@@ -82,7 +82,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
     const int t0 = blockIdx.x * N1;  // first input frame of this workgroup
-    const int b = blockIdx.z;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int Lp = a.L;
     const int L = a.lens ? min(max(a.lens[b], 0) * a.len_mul, a.L) : a.L;  // valid input rows of this utterance (ragged batches)
     if (t0 >= L) return;

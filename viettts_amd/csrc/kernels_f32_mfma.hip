@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
     }
     const int t0 = tile * NT;
     const int m0 = blockIdx.y * MT + wm * (MT / T::WM);  // first output channel of this wave
-    const int b = blockIdx.z;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const float slope = a.slope_in;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
 
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void convT1d_f32_mfma_k(ConvArgs a) {
 
     const int q0 = blockIdx.x * NT;
     const int m0 = blockIdx.y * MT + wm * (MT / T::WM);
-    const int b = blockIdx.z;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int L = a.L;
     const float slope = a.slope_in;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;

@@ -55,6 +55,7 @@ struct ConvArgs {
     int tanh_out;        // apply tanh to the result (conv_post)
     float* pre_act;      // optional copy of the pre-tanh value (same indexing as y) or nullptr
     int tile_pref;       // MFMA time-tile choice: 0 = by problem size, 1 = wide, 2 = narrow (tests)
+    int zrev;            // MFMA kernels: 1 = utterance = gridDim.z - 1 - blockIdx.z (engine.hip: next_zrev)
 };
 
 // ---- generic (any shape) fp32 kernels: kernels_generic.hip -------------------------------
@@ -106,6 +107,7 @@ struct BConvArgs {
     int acc_add;          // y = y + v   (MRF accumulate)
     int tile_pref;        // fused-pair tile width: 0 = by launch size, 1 = wide, 2 = narrow (option "tiles"; tests run both on short inputs)
     float div;            // then the MRF mean v / div as v * (1 / div) (bf16_common.h: mrf_recip), 1 = none
+    int zrev;             // 1 = utterance = gridDim.z - 1 - blockIdx.z: the launch walks the batch backwards (engine.hip: next_zrev)
     unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE): per-workgroup s_memtime stamps; else unused
 };
 
