@@ -1,6 +1,7 @@
 #!/bin/bash
 # consecutive launches walk the batch in alternating directions (env VTTS_ZREV=1): the consumer starts with the utterances the producer wrote last (Infinity Cache)
 O=gpurun_out/r03_exp40; mkdir -p $O
+# (the env switch of this experiment became the engine option "zigzag", default 1)
 VTTS_ZREV=1 timeout 600 python -m pytest tests/test_gpu_bf16.py -m gpu -q -x --timeout 600 -k "golden or ragged or invariance or edge_lengths" 2>&1 | tail -1
 for r in 1 2 3; do for z in 0 1; do
   echo -n "zrev $z  "
