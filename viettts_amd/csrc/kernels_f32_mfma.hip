@@ -204,8 +204,12 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
 //                                          CIN  COUT KS  MT   NT  WM WN CK  NWC
 template <int KS> using Tile256 = ConvTile<256, 256, KS, 128, 128, 2, 2, 64, false>;
 template <int KS> using Tile128 = ConvTile<128, 128, KS, 128, 128, 2, 2, 64, false>;
-template <int KS> using Tile64 = ConvTile<64, 64, KS, 64, 128, 2, 2, 64, false>;
-template <int KS> using Tile32 = ConvTile<32, 32, KS, 32, 256, 1, 4, 32, false>;
+// C <= 64: the "narrow" geometry is also the one for large launches since round 3 — 30.7 / 23.5 KB of LDS per workgroup instead of 47 / 39, i.e. five or
+// six workgroups per CU instead of three: these convolutions are bound by the latency of their staging / epilogue phases, not by halo bytes
+// (64 x 1024 frames: 378.9 -> 367.2 ms per pass; twice as WIDE tiles 429 ms, at C >= 128 too 535 ms; narrow tiles at C >= 128 383 ms; the
+// transposed convolutions' tiles half as wide: no change; gpurun_out/r03_exp45)
+template <int KS> using Tile64 = ConvTile<64, 64, KS, 64, 64, 2, 2, 64, false>;
+template <int KS> using Tile32 = ConvTile<32, 32, KS, 32, 128, 1, 4, 32, false>;
 using TilePre = ConvTile<80, 512, 7, 128, 64, 4, 1, 80, true>;  // conv_pre: mel [T][80] -> [512][T]
 // narrow time tiles for short inputs (batch-1 latency): same math, 4x / 2x more workgroups
 template <int KS> using Tile256S = ConvTile<256, 256, KS, 128, 32, 4, 1, 64, false>;
