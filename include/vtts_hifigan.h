@@ -179,7 +179,8 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "fuse"      bf16: 2 = fused ResBlock pairs + the whole-ResBlock kernel of the C = 32 stage where it is the faster
  *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
- *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another
+ *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another;
+ *               0 (default) = the engine's choice: fp32 two streams (a large batch as half-size passes), bf16 one
  *   "chains"    1 (default) = on a small single-micro-batch launch (B * T <= 2048 frames) the ResBlocks of a stage run side by side on
  *               parallel streams with scratch of their own: the fp32 engine combines their outputs afterwards, the bf16 engine chains the
  *               accumulating epilogues by events in the sequential order — the same additions (and bf16 roundings) in the same

@@ -60,7 +60,11 @@ def test_plan_matches_python_inventory(lib):
     ws = C.c_size_t(0)
     _lib.check(lib, lib.vtts_hifigan_set_option(h, b"microbatch", 1))
     _lib.check(lib, lib.vtts_hifigan_workspace_bytes(h, 64, 1024, C.byref(ws)))
-    assert ws.value == 4 * 8192 * 1024 * 4  # four [C][L] buffers of the widest stage, one utterance
+    assert ws.value == 2 * 4 * 8192 * 1024 * 4  # fp32 default: two micro-batches in flight, each four [C][L] buffers of the widest stage, one utterance
+    _lib.check(lib, lib.vtts_hifigan_set_option(h, b"streams", 1))
+    _lib.check(lib, lib.vtts_hifigan_workspace_bytes(h, 64, 1024, C.byref(ws)))
+    assert ws.value == 4 * 8192 * 1024 * 4
+    _lib.check(lib, lib.vtts_hifigan_set_option(h, b"streams", 0))
     hop = C.c_int64(0)
     _lib.check(lib, lib.vtts_hifigan_get_option(h, b"hop", C.byref(hop)))
     assert hop.value == 256

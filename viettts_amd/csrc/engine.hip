@@ -106,7 +106,7 @@ struct vtts_hifigan {
     int cur_T = 0;                  // ... of the T allocated
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
-    int64_t opt_streams = 1;         // micro-batches in flight on separate HIP streams (1..4)
+    int64_t opt_streams = 0;         // micro-batches in flight on separate HIP streams (1..4; 0 = by engine: fp32 2, bf16 1 — auto_streams)
     int64_t opt_graph = 1;           // small launches: replay a captured hipGraph once the same buffers were seen twice (0 = always eager)
     struct GraphEntry {
         const void* mel = nullptr;
@@ -573,13 +573,19 @@ size_t max_act_elems(const vtts_hifigan* h, int T) {
     return best;
 }
 
+// The fp32 engine runs a large batch as two half-size passes on two streams (one pass's launch tails and memory phases under the other's MFMAs:
+// 64 x 1024 frames 366.5 -> 363.9 ms, gpurun_out/r03_exp35 and the sweep after r03_exp45).  The bf16 engine gains 1.5 % the same way
+// (profiles/r03_c_narrow_stage_findings.md) but stays on one stream: bench.py's roofline times the dominant kernel's launches with HIP events,
+// which is only the kernel's own duration while nothing else shares the GPU.
+int auto_streams(const vtts_hifigan* h) { return h->opt_streams > 0 ? (int)h->opt_streams : (h->dtype == VTTS_F32 ? 2 : 1); }
+
 int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     if (h->opt_microbatch > 0) return (int)std::min<int64_t>(h->opt_microbatch, B);
     // Enough frames per pass that every launch is many rounds of workgroups on the 256 CUs: with few
     // rounds the last, partly filled one costs 10-20 % (measured: bf16 61.6 ms/step at 4096 frames per
     // pass, 49.9 ms at 65536).  fp32 tiles are 2-4x narrower, so fewer frames reach the same round count.
     // (round 3: the fp32 engine too — 16384 frames per pass measured 388.4 ms per 64 x 1024 batch, 65536 frames 380.7 ms; the 8.6 GB of workspace are 3 % of the HBM)
-    const int frames = 65536;
+    const int frames = (h->dtype == VTTS_F32 && auto_streams(h) >= 2) ? 32768 : 65536;
     int mb = (frames + T - 1) / T;
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
@@ -638,7 +644,7 @@ struct Taps {
 int num_streams(const vtts_hifigan* h, int B, int T) {
     const int mb = pick_microbatch(h, B, T);
     const int nmb = (B + mb - 1) / mb;
-    int n = (int)h->opt_streams;
+    int n = auto_streams(h);
     if (n > nmb) n = nmb;
     return n < 1 ? 1 : n;
 }
@@ -1424,7 +1430,7 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
         if (value < 0 || value > 3) return fail(VTTS_ERR_INVALID, "fuse must be 0 (per convolution), 1 (pairs), 2 (pairs + C=32 ResBlocks where faster) or 3 (... wherever supported)");
         h->opt_fuse = value;
     } else if (!strcmp(name, "streams")) {
-        if (value < 1 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4");
+        if (value < 0 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4 (0 = the engine's default)");
         h->opt_streams = value;
     } else if (!strcmp(name, "graph")) {
         if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "graph must be 0 (always eager) or 1 (small launches replay a captured hipGraph)");
