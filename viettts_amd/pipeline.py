@@ -92,11 +92,13 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
             fr = [gfr[ok[r]] for r in rows]
             batch = mel_dev[torch.tensor(rows, device=mel_dev.device), : max(fr)].contiguous()  # a device-side gather (plumbing)
             if ragged:
-                generator.set_option("microbatch", len(rows))  # one pass for the batch (the engine's own cut is PASS_FRAMES of PADDED frames)
+                prev = generator.get_option("microbatch")
+                if prev == 0:
+                    generator.set_option("microbatch", len(rows))  # one pass for the batch (the engine's own cut is PASS_FRAMES of PADDED frames)
                 try:
                     w = generator.forward_ragged(batch, fr)
                 finally:
-                    generator.set_option("microbatch", 0)
+                    generator.set_option("microbatch", prev)  # a caller's own setting is left alone
             else:
                 w = generator(batch)
             host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
