@@ -194,6 +194,8 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
  *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.
  *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
+ * Read-only (get_option): "hop" (samples per mel frame), "max_frames_per_pass" (longest utterance one pass takes; longer ones go through the
+ * chunk scheduler), "pass_frames" (mel frames per pass the launches are sized for: schedulers that build batches aim at it), "graphs_cached".
  */
 int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value);
 int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, int64_t* value);

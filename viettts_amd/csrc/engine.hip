@@ -579,13 +579,16 @@ size_t max_act_elems(const vtts_hifigan* h, int T) {
 // which is only the kernel's own duration while nothing else shares the GPU.
 int auto_streams(const vtts_hifigan* h) { return h->opt_streams > 0 ? (int)h->opt_streams : (h->dtype == VTTS_F32 ? 2 : 1); }
 
+// mel frames per pass the launches are sized for (option "pass_frames", read by the Python schedulers that build the batches)
+int pass_frames(const vtts_hifigan* h) { return (h->dtype == VTTS_F32 && auto_streams(h) >= 2) ? 32768 : 65536; }
+
 int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     if (h->opt_microbatch > 0) return (int)std::min<int64_t>(h->opt_microbatch, B);
     // Enough frames per pass that every launch is many rounds of workgroups on the 256 CUs: with few
     // rounds the last, partly filled one costs 10-20 % (measured: bf16 61.6 ms/step at 4096 frames per
     // pass, 49.9 ms at 65536).  fp32 tiles are 2-4x narrower, so fewer frames reach the same round count.
     // (round 3: the fp32 engine too — 16384 frames per pass measured 388.4 ms per 64 x 1024 batch, 65536 frames 380.7 ms; the 8.6 GB of workspace are 3 % of the HBM)
-    const int frames = (h->dtype == VTTS_F32 && auto_streams(h) >= 2) ? 32768 : 65536;
+    const int frames = pass_frames(h);
     int mb = (frames + T - 1) / T;
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
@@ -1474,6 +1477,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
         const size_t per = max_act_elems(h, 1) * (h->dtype == VTTS_BF16 ? 2 : sizeof(float));
         *value = (int64_t)((((size_t)1 << 31) + per - 1) / per);
     }
+    else if (!strcmp(name, "pass_frames")) *value = pass_frames(h);
     else if (!strcmp(name, "profile_C")) *value = h->prof_C;
     else if (!strcmp(name, "profile_K")) *value = h->prof_K;
     else return fail(VTTS_ERR_INVALID, "unknown option '%s'", name);

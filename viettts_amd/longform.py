@@ -18,7 +18,15 @@ import torch
 from .dist import HALO_FRAMES, Chunk, plan_chunks, shard_chunks
 
 
-PASS_FRAMES = 65536  # mel frames per pass through the generator the engines are sized for (engine.hip: pick_microbatch)
+PASS_FRAMES = 65536  # fallback for generators without the "pass_frames" option; mel frames per pass through the generator the engines are sized for (engine.hip: pick_microbatch)
+
+
+def _pass_frames(gen) -> int:
+    """The engine's own figure (engine.hip: pass_frames) where the generator exposes it."""
+    try:
+        return int(gen.get_option("pass_frames"))
+    except Exception:
+        return PASS_FRAMES
 
 
 def _run_group(gen, mel: torch.Tensor, chunks: Sequence[Chunk], out: torch.Tensor, max_batch: int) -> None:
@@ -27,7 +35,7 @@ def _run_group(gen, mel: torch.Tensor, chunks: Sequence[Chunk], out: torch.Tenso
     (a 10-minute utterance in 512-frame chunks: all 73 after the first; 28.6 -> 26.3 ms against 16 per pass)."""
     hop = gen.hop
     if max_batch <= 0 and chunks:
-        max_batch = max(1, PASS_FRAMES // max(1, chunks[0].hi - chunks[0].lo))
+        max_batch = max(1, _pass_frames(gen) // max(1, chunks[0].hi - chunks[0].lo))
     for i in range(0, len(chunks), max_batch):
         grp = chunks[i : i + max_batch]
         batch = torch.stack([mel[c.lo : c.hi] for c in grp]).contiguous()

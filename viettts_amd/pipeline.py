@@ -17,13 +17,14 @@ import numpy as np
 import torch
 
 from .dist import shard_utterances
+from .longform import _pass_frames
 from .nat import text2mel as t2m
 
 
-PASS_FRAMES = 65536  # mel frames per pass the generator's launches are sized for (engine.hip: pick_microbatch)
+PASS_FRAMES = 65536  # fallback for generators without the "pass_frames" option; mel frames per pass the generator's launches are sized for (engine.hip: pick_microbatch)
 
 
-def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: int = 0) -> List[List[int]]:
+def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: int = 0, pass_frames: int = PASS_FRAMES) -> List[List[int]]:
     """Cut ``rows`` (sorted by ascending ``frames``) into the generator's ragged batches.  gen_batch > 0: at most that many sentences
     per batch.  gen_batch = 0: as few passes as PASS_FRAMES of REAL frames each allow (the ragged kernels skip the tiles past an
     utterance's end, so padding costs workspace, not time), the passes balanced by frames: 256 transcript sentences (54.7k frames,
@@ -34,7 +35,7 @@ def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: in
     if gen_batch > 0:
         return [rows[i : i + gen_batch] for i in range(0, len(rows), gen_batch)]
     total = int(sum(frames))
-    k = max(1, -(-total // int(PASS_FRAMES * 1.25)))
+    k = max(1, -(-total // int(pass_frames * 1.25)))
     out, acc, cut = [[]], 0, 1
     for r, f in zip(rows, frames):
         if acc >= total * cut / k and cut < k and out[-1]:
@@ -88,7 +89,7 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
         todo = sorted((r for r, k in enumerate(ok) if gfr[k] > 0), key=lambda r: gfr[ok[r]])
         pending = []
-        for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1):
+        for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, _pass_frames(generator)):
             fr = [gfr[ok[r]] for r in rows]
             batch = mel_dev[torch.tensor(rows, device=mel_dev.device), : max(fr)].contiguous()  # a device-side gather (plumbing)
             if ragged:
