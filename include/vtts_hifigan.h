@@ -180,7 +180,9 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
  *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another;
- *               0 (default) = the engine's choice: fp32 two streams (a large batch as half-size passes), bf16 one
+ *               0 (default) = the engine's choice: two streams, a large batch (more than 32768 frames) as equal micro-batches of at
+ *               most 32768 frames (same samples as one pass: micro-batches are independent); 1 = everything on the caller's stream
+ *               (what bench.py's roofline calibration pass and the rocprofv3 profiles use: a kernel's duration is its own)
  *   "chains"    1 (default) = on a small single-micro-batch launch (B * T <= 2048 frames) the ResBlocks of a stage run side by side on
  *               parallel streams with scratch of their own: the fp32 engine combines their outputs afterwards, the bf16 engine chains the
  *               accumulating epilogues by events in the sequential order — the same additions (and bf16 roundings) in the same
@@ -194,8 +196,10 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
  *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.
  *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
- * Read-only (get_option): "hop" (samples per mel frame), "max_frames_per_pass" (longest utterance one pass takes; longer ones go through the
- * chunk scheduler), "pass_frames" (mel frames per pass the launches are sized for: schedulers that build batches aim at it), "graphs_cached".
+ * Read-only (get_option): "hop" (samples per mel frame), "max_frames_per_pass" (the SMALLEST T the engine refuses: forward() takes
+ * T < max_frames_per_pass, an utterance of that many frames or more goes through the chunk scheduler), "pass_frames" (mel frames per call
+ * the launches are sized for: schedulers that build batches aim at it), "graphs_cached".
+ * Setting an option to the value it already has is a no-op (captured graphs stay valid).
  */
 int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value);
 int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, int64_t* value);

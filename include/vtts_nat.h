@@ -133,6 +133,24 @@ int vtts_nat_acoustic_keep_masks_haiku_mode(const vtts_nat_acoustic* h, uint32_t
 int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
                               const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
                               const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * forward() that hands the mel over in GROUPS of rows as the decoder finishes them (the text -> waveform pipeline, BASELINE configs[3];
+ * the reference synthesises one sentence per process, vietTTS/synthesizer.py:33-39, and has nothing to overlap).  The decoder is a chain
+ * of Fmax dependent steps that barely loads the chip; a sentence's mel is complete after ITS last frame, long before the batch's.
+ *   group_row0   HOST [ngroups + 1]: group g = rows [group_row0[g], group_row0[g + 1]); group_row0[0] = 0, group_row0[ngroups] = B
+ *   group_frames HOST [ngroups]: the largest nframes among the group's rows (1 .. Fmax)
+ * The arithmetic of every row is that of forward() (same kernels, same order: bit-identical mel).  After decoder frame
+ * group_frames[g] - 1 the group's postnet runs on a stream of the handle's own beside the remaining decoder steps, and
+ * vtts_nat_acoustic_wait_group(h, g, consumer_stream) makes `consumer_stream` wait for exactly that (rows of group g of mel_dev
+ * complete) — e.g. the stream a vocoder runs on.  `stream` itself waits for every group before the call's work on it ends, so code
+ * that ignores the groups sees forward()'s semantics.  Sort the rows by descending nframes to make the groups finish one after another.
+ */
+int vtts_nat_acoustic_forward_groups(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev,
+                                     const float* durations_dev, const int32_t* nframes_dev, int B, int Lmax, int Fmax,
+                                     const uint8_t* keep_dev, float* mel_dev, void* workspace, size_t workspace_bytes, void* stream,
+                                     int ngroups, const int32_t* group_row0, const int32_t* group_frames);
+/* Valid for the groups of the handle's LAST forward_groups() call (VTTS_ERR_STATE otherwise). */
+int vtts_nat_acoustic_wait_group(vtts_nat_acoustic* h, int group, void* stream);
 
 #ifdef __cplusplus
 }

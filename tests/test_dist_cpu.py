@@ -46,6 +46,22 @@ def test_plan_chunks_cover_exactly(T, chunk):
             assert all(c.index % world == r for c in s)
 
 
+def test_blob_checksum_sees_flips_swaps_and_length():
+    from viettts_amd.dist import blob_checksum, verify_blob_on_all_ranks
+
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(0, 256, (4099,), dtype=torch.uint8, generator=g)  # not a multiple of 8: the tail is zero-padded
+    base = blob_checksum(a)
+    assert base == blob_checksum(a.clone()) == verify_blob_on_all_ranks(a)  # one process: nothing to compare, the checksum itself
+    b = a.clone()
+    b[4098] ^= 1
+    assert blob_checksum(b) != base
+    c = a.clone()
+    c[0:8], c[8:16] = a[8:16].clone(), a[0:8].clone()  # two whole words swapped: a plain sum would not notice
+    assert blob_checksum(c) != base
+    assert blob_checksum(torch.cat([a, torch.ones(8, dtype=torch.uint8)])) != base
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -98,7 +114,28 @@ def _worker(rank, world, port, q):
     m = vdist.setup_model_dp(FakeModel(), lambda mm: mm.load_params(7 + rank), info)  # a rank-dependent seed: only rank 0's may win
     want = (torch.arange(4096, dtype=torch.int64) * 7 % 253).to(torch.uint8)
     ok_bcast = ok_bcast and bool(torch.equal(m._blob, want)) and m.loaded == (rank == 0) and m.adopted == (rank != 0)
-    q.put((rank, ok_bcast, ok_gather))
+    # every rank checksums the blob it ended up with and the checksums are all-reduced (MIN, MAX): equal here ...
+    st = {}
+    m2 = vdist.setup_model_dp(FakeModel(), lambda mm: mm.load_params(11), info, st)
+    ok_sum = st.get("blob_checksum_equal") is True and st.get("backend") == "gloo" and st["blob_checksum"] == f"{vdist.blob_checksum(m2._blob) & 0xFFFFFFFFFFFFFFFF:#018x}"
+    # ... and a transfer that damages ONE byte on ONE rank stops EVERY rank at start-up
+    real_bcast = vdist.broadcast_packed_weights
+
+    def damaged_bcast(blob, src=0):
+        real_bcast(blob, src)
+        if rank == 1:
+            blob[1234] ^= 0x10
+        return blob
+
+    vdist.broadcast_packed_weights = damaged_bcast
+    try:
+        vdist.setup_model_dp(FakeModel(), lambda mm: mm.load_params(13), info)
+        ok_sum = False
+    except RuntimeError as e:
+        ok_sum = ok_sum and "different blobs" in str(e)
+    finally:
+        vdist.broadcast_packed_weights = real_bcast
+    q.put((rank, ok_bcast and ok_sum, ok_gather))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -122,6 +159,32 @@ def test_generator_batches_cover_every_sentence_once_and_balance_by_frames():
         capped = _generator_batches(rows, fr, 64)
         assert [r for b in capped for r in b] == rows and max(len(b) for b in capped) <= 64
     assert _generator_batches([], []) == []
+
+
+def test_generator_batches_bound_the_padded_size():
+    """a long-tailed shard (500 sentences of ~100 frames and one of 1000) must not become one pass of 500 000 padded frames."""
+    from viettts_amd.pipeline import PASS_FRAMES, _generator_batches
+
+    fr = sorted([100] * 500 + [1000])
+    out = _generator_batches(list(range(501)), fr)
+    assert [r for b in out for r in b] == list(range(501))
+    assert all(len(b) * fr[b[-1]] <= 2 * PASS_FRAMES for b in out) and len(out) == 2
+
+
+def test_overlap_groups_are_contiguous_and_balanced():
+    """viettts_amd/pipeline.py::_overlap_groups — the row groups whose mel the acoustic model hands over one after another."""
+    import random
+
+    from viettts_amd.pipeline import _overlap_groups
+
+    rnd = random.Random(9)
+    for n, ng in ((256, 4), (12, 3), (5, 8), (1, 4), (64, 1)):
+        fr = sorted((rnd.randint(60, 281) for _ in range(n)), reverse=True)
+        b = _overlap_groups(fr, ng)
+        assert b[0] == 0 and b[-1] == n and all(x < y for x, y in zip(b, b[1:])) and len(b) - 1 <= max(1, min(ng, n))
+        if n == 256:
+            sums = [sum(fr[b[i] : b[i + 1]]) for i in range(len(b) - 1)]
+            assert len(sums) == 4 and max(sums) - min(sums) <= 2 * 281
 
 
 def test_gloo_world2_broadcast_and_gather():

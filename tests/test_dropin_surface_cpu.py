@@ -51,17 +51,22 @@ def test_missing_checkpoints_raise_like_the_reference(tmp_path, monkeypatch):
         t2m_ref.predict_duration([1, 2, 3])
 
 
-def test_committed_counters_belong_to_the_sources_in_the_tree():
+def test_committed_counters_are_well_formed_and_say_which_build_they_belong_to():
     """bench.py reports roofline.traffic / roofline.mfma_util from profiles/counters_<dtype>.json only while the digest recorded there equals the
-    digest of the kernel sources (tools/profile_final.sh writes it): a kernel change without a fresh profile run would silently drop them from the
-    bench line — fail here instead, where it is cheap to notice."""
+    digest of the kernel sources (tools/profile_final.sh writes it).  A kernel change without a fresh profile run makes bench.py report null plus
+    the reason — correct behaviour, so a digest that lags the sources is a WARNING here, not a failure (correctness CI must not depend on a
+    profiling artefact being re-collected on a GPU: ADVICE r03); the files' structure is asserted."""
     import json
+    import warnings
 
     from viettts_amd.csrc.build import _digest
 
     for dt in ("bf16", "f32"):
         rec = json.load(open(REPO / "profiles" / f"counters_{dt}.json"))
-        assert rec["source_digest"] == _digest(), f"profiles/counters_{dt}.json is from another build: re-run tools/profile_final.sh (tools/r03_verify.sh) and copy the set"
+        if rec["source_digest"] != _digest():
+            warnings.warn(f"profiles/counters_{dt}.json is from another build ({rec['source_digest'][:12]} vs {_digest()[:12]}): bench.py will report "
+                          f"roofline.traffic / mfma_util as null until tools/profile_final.sh is re-run and the set copied")
+        assert len(rec["source_digest"]) == 64
         assert rec["time_weighted_mfma_util_resblock_kernels"] and len(rec["kernels"]) > 10
         tag = rec["tag"]
         assert (REPO / "profiles" / f"{tag}_pmc.md").exists() and (REPO / "profiles" / f"{tag}_kernel_stats.md").exists()

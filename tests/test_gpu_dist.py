@@ -28,6 +28,8 @@ def test_two_ranks_share_one_gpu_and_shard_both_legs():
     assert "cpu_baseline" in d and d["cpu_baseline"] is None and "N = 2" in d["cpu_baseline_skipped"]
     wb = d["weights_broadcast"]
     assert wb["backend"] == "gloo" and wb["ranks_in_group"] == 2 and wb["bytes"] > 20e6  # ONE broadcast of the packed blob, then no collective on the data path
+    assert wb["blob_checksum_equal"] is True and wb["blob_checksum"].startswith("0x")  # every rank checksummed what it received: MIN == MAX over the ranks
+    assert len(d["ms_per_step_per_rank"]) == 2 and max(d["ms_per_step_per_rank"]) == pytest.approx(d["ms_per_step"], rel=1e-6)  # a straggler would show
     # sharded == unsharded, leg by leg: the same sentences / chunks were synthesised, each exactly once
     import bench
 

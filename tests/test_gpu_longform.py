@@ -43,6 +43,63 @@ def test_chunked_equals_unchunked(gen):
     assert (a + b - full).abs().max().item() < 5e-6
 
 
+@pytest.fixture(scope="module")
+def gen_bf16():
+    from viettts_amd.hifigan.generator import Generator
+
+    g = Generator(V1, device="cuda:0", dtype="bf16")
+    g.load_params(synthetic_params(V1, 4321, "scaled"))
+    yield g
+    g.close()
+
+
+def _snr_db(got, want):
+    return float(10 * np.log10((want ** 2).mean() / max(((got - want) ** 2).mean(), 1e-300)))
+
+
+@pytest.mark.parametrize("T,chunk,with_oracle", [(700, 128, True), (1500, 256, False)], ids=["T700c128-oracle", "T1500c256"])
+def test_chunked_equals_unchunked_bf16_default_pass(gen_bf16, T, chunk, with_oracle, capsys):
+    """What bench.py's ``longform_10min`` leg runs, at a length the oracle can follow: the **bf16** engine through ``synthesize_chunked``
+    with its DEFAULTS (``max_batch = 0``: the first chunk alone, then every other chunk of one fed length in ONE full-size pass whose
+    kept samples leave in one strided copy), a ragged last chunk, and the chunk-DP split over two ranks.  Against
+    (a) the un-chunked bf16 output (a 13-frame halo covers the +-12.71-frame receptive field and a sample's arithmetic does not depend
+        on where its tile lies, so the kept samples are expected bit-identical; asserted within the bf16 bound, reported),
+    (b) ``oracle.hifigan_oracle.generator_forward`` in fp64 on the whole utterance — the reference's mel2wave semantics
+        (vietTTS/hifigan/mel2wave.py:37-40), bf16 bounds of tests/test_gpu_bf16.py: max-abs < 0.03, waveform SNR > 35 dB."""
+    from oracle.hifigan_oracle import generator_forward
+    from viettts_amd.longform import synthesize_chunked
+
+    params = synthetic_params(V1, 4321, "scaled")
+    mel_h = synthetic_mel(1, T, 3)
+    mel = torch.from_numpy(mel_h).to("cuda:0")
+    assert gen_bf16.get_option("microbatch") == 0 and gen_bf16.get_option("streams") == 0
+    full = gen_bf16(mel)[0].clone()
+    timing = {}
+    got = synthesize_chunked(gen_bf16, mel[0], chunk_frames=chunk, timing=timing)  # defaults: halo 13, max_batch 0
+    assert got.shape == full.shape and timing["chunks"] == -(-T // chunk) and T % chunk != 0
+    d_self = float((got - full).abs().max())
+    n_diff = int((got != full).sum())
+    with capsys.disabled():
+        print(f"\n[bf16 long-form T={T} chunk={chunk}: {timing['chunks']} chunks] chunked vs un-chunked bf16: max|d| {d_self:.3e} ({n_diff} samples differ)")
+    assert d_self < 0.03
+    if with_oracle:  # ~10 s of numpy per 256 frames: the shorter case only
+        want = generator_forward(params, mel_h, V1, np.float64)[0, :, 0]
+        g64 = got.double().cpu().numpy()
+        e_or, snr = float(np.abs(g64 - want).max()), _snr_db(g64, want)
+        e_full = float(np.abs(full.double().cpu().numpy() - want).max())
+        with capsys.disabled():
+            print(f"[bf16 long-form T={T}] chunked vs fp64 oracle: max|d| {e_or:.3e}, SNR {snr:.1f} dB (un-chunked vs oracle {e_full:.3e})")
+        assert e_or < 0.03 and snr > 35.0, (e_or, snr)
+    assert bool(torch.isfinite(got).all()) and float(got.abs().max()) <= 1.0
+    # chunk c -> rank c mod 2: the two ranks' pieces are disjoint and add up to the single-rank result, bit for bit
+    a = synthesize_chunked(gen_bf16, mel[0], chunk_frames=chunk, rank=0, world=2)
+    b = synthesize_chunked(gen_bf16, mel[0], chunk_frames=chunk, rank=1, world=2)
+    assert ((a != 0) & (b != 0)).sum().item() == 0
+    assert torch.equal(a + b, got)
+    # an explicit small pass size walks the same chunks 3 at a time: same samples
+    assert torch.equal(synthesize_chunked(gen_bf16, mel[0], chunk_frames=chunk, max_batch=3), got)
+
+
 def test_dp_setup_single_rank(gen):
     from viettts_amd import dist as vdist
     from viettts_amd.hifigan.generator import Generator

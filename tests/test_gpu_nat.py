@@ -264,6 +264,73 @@ def test_pipeline_sharded_equals_unsharded(model, acoustic):
         gen.close()
 
 
+def test_pipeline_waveforms_equal_each_sentence_alone_and_the_oracle(model, acoustic, capsys):
+    """What bench.py's ``pipeline_256`` leg runs, against something other than itself.  12 sentences of the reference's demo transcript
+    (token ids pinned to the reference's text2tokens: tests/test_frontend_cpu.py) through ``synthesize_sentences`` — length-sorted
+    rows, masks seeded by the global sentence index, the generator's ragged passes, the pinned read-back; with the acoustic model and
+    the generator overlapped in groups (the default for large shards) and one after the other:
+      (a) the two schedules give the same samples, bit for bit;
+      (b) every waveform is bit-identical to the same sentence run ALONE: duration model -> frame rules -> acoustic model -> forward_ragged;
+      (c) 8 of them are within the bf16 bounds (tests/test_gpu_bf16.py: max-abs < 0.03; waveform SNR > 35 dB) of the ORACLE chain
+          nat_oracle.duration_model -> the reference's frame rules -> nat_oracle.acoustic_inference on the same threefry masks ->
+          hifigan_oracle.generator_forward (fp64) — vietTTS/synthesizer.py:33-39 = text2mel, then mel2wave — with equal frame counts."""
+    from pathlib import Path
+
+    from oracle.hifigan_oracle import generator_forward
+    from viettts_amd.hifigan.config import V1
+    from viettts_amd.hifigan.generator import Generator
+    from viettts_amd.hifigan.synth import synthetic_params
+    from viettts_amd.nat.synth import transcript_sentences
+    from viettts_amd.pipeline import synthesize_sentences
+
+    dm, Pd, Sd = model
+    am, Pa, Sa = acoustic
+    tdir = Path(__file__).parent / "golden" / "text"
+    sents = transcript_sentences(12, tdir / "transcript.txt", tdir / "lexicon.txt")
+    sil, seed = 0.05, 7
+    params = synthetic_params(V1, 4321, "scaled")
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(params)
+    try:
+        tm = {}
+        over = synthesize_sentences(sents, dm, am, gen, silence_duration=sil, dropout_seed=seed, overlap_groups=3, timing=tm)
+        assert tm["overlap_groups"] == 3
+        serial = synthesize_sentences(sents, dm, am, gen, silence_duration=sil, dropout_seed=seed, overlap_groups=1)
+        assert sorted(over) == sorted(serial) == list(range(12))
+        for i in range(12):
+            assert np.array_equal(over[i], serial[i]), i  # (a)
+        frames_gpu = {}
+        for i in range(12):  # (b)
+            secs = dm([sents[i]])
+            fr, nfr, trail = t2m.frame_plan([sents[i]], secs, sil)
+            g = nfr[0] - trail[0]
+            frames_gpu[i] = (nfr[0], trail[0])
+            mel = am([sents[i]], [fr[0]], [nfr[0]], dropout_seeds=[seed + i], to_host=False)
+            w = gen.forward_ragged(mel[:, :g].contiguous(), [g])[0].cpu().numpy()
+            assert serial[i].shape == (256 * g,) and np.array_equal(w, serial[i]), i
+            assert np.array_equal(gen(mel[:, :g].contiguous())[0].cpu().numpy(), serial[i]), i  # ... and to the plain entry point
+        worst_e, worst_snr = 0.0, 1e9
+        short = sorted(range(12), key=lambda i: serial[i].shape[0])[:8]
+        for i in short:  # (c)
+            tok = np.array(sents[i])
+            d = no.duration_model(Pd, Sd, tok, dtype=np.float32)
+            fr, nfr, trail = t2m.frame_plan([sents[i]], [d], sil)
+            assert (nfr[0], trail[0]) == frames_gpu[i], i  # integer frame counts: equal (BASELINE.json)
+            masks = no.threefry_keep_masks(seed + i, nfr[0], 256)
+            mel = no.acoustic_inference(Pa, Sa, tok, fr[0], nfr[0], prenet_masks=lambda f, m=masks: (m[f, 0], m[f, 1]), dtype=np.float64)
+            g = nfr[0] - trail[0]
+            want = generator_forward(params, mel[None, :g].astype(np.float32), V1, np.float64)[0, :, 0]
+            got = serial[i].astype(np.float64)
+            e = float(np.abs(got - want).max())
+            snr = float(10 * np.log10((want ** 2).mean() / ((got - want) ** 2).mean()))
+            worst_e, worst_snr = max(worst_e, e), min(worst_snr, snr)
+            assert e < 0.03 and snr > 35.0, (i, e, snr)
+        with capsys.disabled():
+            print(f"\n[pipeline vs the oracle chain, 8 sentences, {sum(serial[i].shape[0] for i in short)} samples] worst max|dy| {worst_e:.3e}, worst SNR {worst_snr:.1f} dB")
+    finally:
+        gen.close()
+
+
 def test_device_keep_masks_equal_the_threefry_restatement(acoustic):
     """Masks drawn by the library on the GPU == oracle/nat_oracle.py::threefry_keep_masks (pinned by Random123's
     known answers on the CPU side), and a sentence's masks do not depend on the batch it is in."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counters for the build you bench.  On one MI355X box:
-#     gpurun --timeout 1500 -- 'bash tools/profile_final.sh r03_final'
+#     gpurun --timeout 1500 -- 'bash tools/profile_final.sh r04_final'
 # runs, for THE SAME bench command (bf16, B = 64 x T = 1024):
 #   1. rocprofv3 --kernel-trace --stats                      -> per-kernel durations
 #   2. rocprofv3 --kernel-trace --pmc <SQ set + GRBM>        -> MfmaUtil, wait shares, LDS bank conflicts
@@ -10,8 +10,10 @@
 #   gpurun_out/<tag>/<tag>_kernel_stats.md, <tag>_pmc.md, counters_bf16.json
 # Copy those three into profiles/ (counters_bf16.json keeps its name): bench.py reports roofline.traffic / roofline.mfma_util from
 # counters_bf16.json only while its `source_digest` equals the digest of the sources the loaded library was built from.
-R=$PWD; T=${1:-r03_final}; O=$R/gpurun_out/$T; mkdir -p $O
-BENCH="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32"
+R=$PWD; T=${1:-r04_final}; O=$R/gpurun_out/$T; mkdir -p $O
+# one stream, one pass of 64: a kernel's duration and counters are its own (the engine's default runs two half-size passes side by side;
+# bench.py's roofline calibration pass times this same schedule)
+BENCH="python $R/bench.py --steps 2 --warmup 1 --streams 1 --microbatch 64 --no-cpu-baseline --no-rtf --no-f32"
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -o r -- $BENCH > $O/trace.log 2>&1
 i=0

@@ -79,6 +79,8 @@ NAT_EXPORTS = (
     "vtts_nat_acoustic_keep_masks_haiku",
     "vtts_nat_acoustic_keep_masks_haiku_mode",
     "vtts_nat_acoustic_forward",
+    "vtts_nat_acoustic_forward_groups",
+    "vtts_nat_acoustic_wait_group",
 )
 
 
@@ -210,6 +212,9 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_acoustic_keep_masks_haiku": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_keep_masks_haiku_mode": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_forward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp]),
+        "vtts_nat_acoustic_forward_groups": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.c_int,
+                                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+        "vtts_nat_acoustic_wait_group": (C.c_int, [vp, C.c_int, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

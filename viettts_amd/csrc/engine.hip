@@ -573,14 +573,20 @@ size_t max_act_elems(const vtts_hifigan* h, int T) {
     return best;
 }
 
-// The fp32 engine runs a large batch as two half-size passes on two streams (one pass's launch tails and memory phases under the other's MFMAs:
-// 64 x 1024 frames 366.5 -> 363.9 ms, gpurun_out/r03_exp35 and the sweep after r03_exp45).  The bf16 engine gains 1.5 % the same way
-// (profiles/r03_c_narrow_stage_findings.md) but stays on one stream: bench.py's roofline times the dominant kernel's launches with HIP events,
-// which is only the kernel's own duration while nothing else shares the GPU.
-int auto_streams(const vtts_hifigan* h) { return h->opt_streams > 0 ? (int)h->opt_streams : (h->dtype == VTTS_F32 ? 2 : 1); }
+// Both engines run a large batch as two half-size passes on two streams: one pass's launch tails and memory phases lie under the other's
+// MFMAs (fp32: 64 x 1024 frames 366.5 -> 363.9 ms, gpurun_out/r03_exp35; bf16 with the zigzag batch order: 39.95 -> 39.32-39.50 ms,
+// profiles/r03_c_narrow_stage_findings.md §4, r03_exp42).  Micro-batches are independent, so the samples do not depend on the schedule
+// (bit-identical: tests/test_gpu_bf16.py::test_ragged_batch_across_micro_batches_and_streams, test_gpu_parity.py).  A kernel's duration is its
+// own only while nothing else shares the GPU: bench.py therefore times the dominant kernel in a one-stream calibration pass of the same build
+// and inputs (option streams = 1), and tools/profile_final.sh profiles that schedule.
+int auto_streams(const vtts_hifigan* h) { return h->opt_streams > 0 ? (int)h->opt_streams : 2; }
 
-// mel frames per pass the launches are sized for (option "pass_frames", read by the Python schedulers that build the batches)
+// mel frames per CALL the Python schedulers build their batches for (option "pass_frames": viettts_amd/longform.py, pipeline.py).  The bf16
+// engine takes 65536 frames per call and cuts them into its micro-batches itself; the fp32 engine's callers hand it one micro-batch at a time.
 int pass_frames(const vtts_hifigan* h) { return (h->dtype == VTTS_F32 && auto_streams(h) >= 2) ? 32768 : 65536; }
+
+// mel frames per micro-batch (one sequence of launches on one stream)
+int microbatch_frames(const vtts_hifigan* h) { return auto_streams(h) >= 2 ? 32768 : 65536; }
 
 int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     if (h->opt_microbatch > 0) return (int)std::min<int64_t>(h->opt_microbatch, B);
@@ -588,10 +594,17 @@ int pick_microbatch(const vtts_hifigan* h, int B, int T) {
     // rounds the last, partly filled one costs 10-20 % (measured: bf16 61.6 ms/step at 4096 frames per
     // pass, 49.9 ms at 65536).  fp32 tiles are 2-4x narrower, so fewer frames reach the same round count.
     // (round 3: the fp32 engine too — 16384 frames per pass measured 388.4 ms per 64 x 1024 batch, 65536 frames 380.7 ms; the 8.6 GB of workspace are 3 % of the HBM)
-    const int frames = pass_frames(h);
+    const int frames = microbatch_frames(h);
     int mb = (frames + T - 1) / T;
     if (mb < 1) mb = 1;
     if (mb > B) mb = B;
+    // equal micro-batches, as many as a multiple of the streams (48 utterances of 1024 frames: 24 + 24, not 32 + 16; 256 sentences padded to
+    // 281 frames: 4 x 64, not 3 x 86 on two streams): the streams finish together
+    int nmb = (B + mb - 1) / mb;
+    const int ns = auto_streams(h);
+    if (nmb > 1 && ns > 1) nmb = (nmb + ns - 1) / ns * ns;
+    if (nmb > B) nmb = B;
+    mb = (B + nmb - 1) / nmb;
     return mb;
 }
 
@@ -1422,6 +1435,10 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
 
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
+    {  // setting an option to the value it has changes nothing: captured graphs stay valid
+        int64_t cur = 0;
+        if (strcmp(name, "profile") && vtts_hifigan_get_option(h, name, &cur) == VTTS_OK && cur == value) return VTTS_OK;
+    }
     ++h->epoch;  // a captured launch sequence reflects the options it was captured under
     if (!strcmp(name, "kernels")) {
         if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "kernels must be 0 (auto) or 1 (generic)");

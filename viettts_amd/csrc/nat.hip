@@ -230,6 +230,18 @@ struct vtts_nat_duration : NatModel {
 };
 struct vtts_nat_acoustic : NatModel {
     vtts_nat_acoustic_cfg cfg;
+    // forward_groups(): the postnet of a group of rows runs on `side` as soon as the decoder has produced the group's last frame
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gates = nullptr;
+    std::vector<hipEvent_t> ev_dec, ev_done;  // per group: decoder frames complete (recorded on the caller's stream) / mel rows complete (on `side`)
+    int groups_valid = 0;
+    ~vtts_nat_acoustic() {
+        for (hipEvent_t e : ev_dec) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_done) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_gates) (void)hipEventDestroy(ev_gates);
+        if (side) (void)hipStreamDestroy(side);
+    }
 };
 
 // ================================================ kernels ================================================
@@ -310,11 +322,11 @@ template <int K, int MR>
 __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__ x, const int* __restrict__ lengths, const float4* __restrict__ wpk,
                                                        const float* __restrict__ bias, const float* __restrict__ inv, const float* __restrict__ mean,
                                                        const float* __restrict__ offset, const float* __restrict__ res, float* __restrict__ y, int Lmax,
-                                                       int Cin, int Cout, int act) {
+                                                       int Cin, int Cout, int act, int tile0) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     constexpr int NR = 2, PL = (K - 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z, t0 = blockIdx.x * 64;
+    const int b = blockIdx.z, t0 = (blockIdx.x + tile0) * 64;  // tile0: a launch may cover the 64-frame tiles [tile0, tile0 + gridDim.x) only
     const int len = lengths[b];
     const int MB = (Cout + 31) / 32, NCS = (Cin + 31) / 32;
     const int mb0 = (blockIdx.y * 4 + wave) * MR;
@@ -517,11 +529,15 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
 // ping-pong by frame parity:
 //   Z[parity][row / 4][Bp][row % 4]  (one 16-byte load per lane = 4 consecutive rows of its sentence: the LSTM step is bound
 //   by the number of vector-memory instructions a CU can issue, and dword loads of the state were 8 of its 9 per iteration),
-//   rows [ h1 (H) | cond_f (E) | p (PN) | h2 (H) ]:  LSTM1 reads rows [H, H+E+PN) of the current
-//   parity then h1 of the previous one; LSTM2 reads rows [0, H+E+PN) of the current parity then h2 of the previous one.
-//   LSTM1's rows are in Haiku's order; LSTM2's Haiku matrix is [x ; h1 ; h2], so pack() permutes its rows into the
-//   state's [h1 ; x ; h2] order on the host (a product's terms are the same, summed in state-row order).  Cell states
-//   c1, c2 as [H][Bp].
+//   rows [ p (PN) | h1 (H) | h2 (H) ]:  LSTM1 reads p of the current parity then h1 of the previous one; LSTM2 reads
+//   [p ; h1] of the current parity then h2 of the previous one.  Haiku's matrices are [cond ; p ; h1] and
+//   [cond ; p ; h1 ; h2] (x = [cond ; p] first): the state order is Haiku's order minus the cond rows.
+//   **The conditioning's share of the gates is hoisted out of the frame loop (round 4):** cond_f is known for every frame
+//   before the loop starts, so G_l[b][f][:] = b_l + cond[b][f] @ W_l[0:E] is ONE fp32-MFMA GEMM per layer ahead of the loop
+//   (nat_conv_mfma_k with one tap, output columns in the step kernel's accumulator order) and a step starts its sums from
+//   G_l[b][f] instead of from the bias: per-frame K 1280 -> 768 (layer 1) and 1792 -> 1280 (layer 2), a third less of the
+//   L2 -> CU weight stream that bounds the step.  Only the first 64 frames' G is computed in front of the loop; the rest runs on
+//   a side stream beside the (latency-bound) first 64 steps.  Cell states c1, c2 as [H][Bp].
 //
 // nat_dec_lstm_k: gates[32 sentences x (8 units x 4 gates)] per wave on the fp32 matrix cores (v_mfma_f32_32x32x2_f32:
 // M = the slice's 32 gate columns ordered 4*unit + gate, N = 32 sentences, K = 2 per instruction).  With that row order a
@@ -543,6 +559,10 @@ struct NatLstmOps {
     const float* bias;   // [4H], gates i, g, f, o
     float* cst;          // cell state [H][Bp]
     float* hout;         // new hidden state, state layout
+    const float* gin;    // optional: this step's gate pre-activations computed ahead of the loop (bias + the contribution of inputs known in
+                         // advance), [sentence][gpitch floats] with the step's 4H values in the order ((slice * 2 + lane / 32) * 4 + unit pair) * 4 + gate:
+                         // a lane's 16 accumulators are 64 contiguous bytes.  nullptr = start from the bias.
+    size_t gpitch;
 };
 template <int NT, int KW>
 __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLstmOps ops1, int KA, int KB, const int* __restrict__ nframes, int f, int B,
@@ -571,17 +591,36 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     const int NIT = (KA + KB) / 8, NWMAX = (NIT + KW - 1) / KW, it_lo = kw * NWMAX;
     const int NW = it_lo >= NIT ? 0 : (NIT - it_lo < NWMAX ? NIT - it_lo : NWMAX);  // this wave's iterations [it_lo, it_lo + NW)
     f32x16 acc[NT][2];
+    if (ops.gin != nullptr && kw == 0) {
+        // the sum starts from the hoisted part (bias + the inputs known ahead of the loop, themselves an MFMA chain in k order)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int b = b0 + 32 * nt + l31;
+            const float4* __restrict__ gp = reinterpret_cast<const float4*>(ops.gin + (size_t)(b < B ? b : B - 1) * ops.gpitch + (size_t)(2 * slice + lh) * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float bv = kw == 0 ? bias[i * H + 8 * slice + 2 * rq + lh] : 0.0f;
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 g4 = gp[rq];
+                acc[nt][0][4 * rq + 0] = g4.x;
+                acc[nt][0][4 * rq + 1] = g4.y;
+                acc[nt][0][4 * rq + 2] = g4.z;
+                acc[nt][0][4 * rq + 3] = g4.w;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[nt][0][4 * rq + i] = bv;
-                acc[nt][1][4 * rq + i] = 0.0f;
+                for (int i = 0; i < 4; ++i) acc[nt][1][4 * rq + i] = 0.0f;
             }
         }
+    } else {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float bv = (kw == 0 && ops.gin == nullptr) ? bias[i * H + 8 * slice + 2 * rq + lh] : 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[nt][0][4 * rq + i] = bv;
+                    acc[nt][1][4 * rq + i] = 0.0f;
+                }
+            }
+    }
     float4 wv[NAT_DEC_PD];
     float4 xv[NAT_DEC_PD][NT];
     const float4* __restrict__ wsl = wpk + (size_t)slice * NIT * 64 + lane;
@@ -807,20 +846,14 @@ __global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsig
     }
 }
 
-// Frame 0's input: h1 = h2 = 0, c = 0 (memset), prenet(0) = 0 (no biases), cond_0 from the upsampler.
-__global__ void nat_dec_init_k(const float* __restrict__ cond, float* __restrict__ zcond, int B, int Bp, int Fmax, int E) {
-    const int b = blockIdx.x;
-    for (int e = threadIdx.x; e < E; e += blockDim.x) zcond[nat_zidx(e, b, Bp)] = cond[(size_t)b * Fmax * E + e];
-}
-
-// mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 and its cond row into the other parity's state.  One
+// mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 into the other parity's state.  One
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
-__global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext, const float* __restrict__ cond,
+__global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext,
                                                               const int* __restrict__ nframes, const float4* __restrict__ f1, const float4* __restrict__ f2,
                                                               const float4* __restrict__ wp, const float* __restrict__ bp,
                                                               const unsigned char* __restrict__ keep, float* __restrict__ mel, int f, int B, int Bp,
-                                                              int Fmax, int E, int PN, int H, int MEL) {
+                                                              int Fmax, int PN, int H, int MEL) {
     extern __shared__ float4 sq[];
     float4* hs = sq;              // [2H]   h1 ; h2 of the 4 sentences
     float4* part = hs + 2 * H;    // [1024] partial sums of the product in flight
@@ -835,9 +868,8 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         any = any || f < nf[s];
     }
     if (!any) return;
-    const int X = E + PN;
     for (int k = g; k < 2 * H; k += 1024) {
-        const float* __restrict__ zr = zcur + nat_zidx(k < H ? k : k + X, b0, Bp);  // the 4 sentences of this row: 16 bytes apart
+        const float* __restrict__ zr = zcur + nat_zidx(PN + k, b0, Bp);  // state rows [p | h1 | h2]; the 4 sentences of a row are 16 bytes apart
         hs[k] = make_float4(zr[0], zr[4], zr[8], zr[12]);
     }
     __syncthreads();
@@ -891,14 +923,6 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     };
     const int nchN = 1024 / PN;
     if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, ((MEL + nchN - 1) / nchN + 3) / 4 * 4);
-    for (int e = g; e < E; e += 1024) {  // cond_{f+1} of the 4 sentences
-        float v[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = b0 + s < B ? cond[((size_t)(b0 + s) * Fmax + f + 1) * E + e] : 0.0f;
-        float* __restrict__ zw = znext + nat_zidx(H + e, b0, Bp);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) zw[4 * s] = v[s];
-    }
     __syncthreads();
     if (g < PN) p1[g] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 0, g);
     __syncthreads();
@@ -906,7 +930,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     __syncthreads();
     if (g < PN) {
         const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
-        float* __restrict__ zw = znext + nat_zidx(H + E + g, b0, Bp);
+        float* __restrict__ zw = znext + nat_zidx(g, b0, Bp);
         zw[0] = r.x; zw[4] = r.y; zw[8] = r.z; zw[12] = r.w;
     }
 }
@@ -950,6 +974,8 @@ int run_token_encoder(const NatModel& m, const std::string& te, int V, int D, co
             o[dir].wpk = reinterpret_cast<const float4*>(m.extra(mod + "#mfma"));
             o[dir].bias = m.dev(mod, "b");
             o[dir].cst = cs + dir * slab;
+            o[dir].gin = nullptr;
+            o[dir].gpitch = 0;
         }
         for (int st = 0; st < Lmax; ++st) {
             for (int dir = 0; dir < 2; ++dir) {
@@ -1059,7 +1085,7 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
     if (!cfg || !out) return failf(VTTS_ERR_INVALID, "null argument");
     const int D = cfg->encoder_dim, V = cfg->vocab_size, H = cfg->decoder_dim, PN = cfg->prenet_dim, MEL = cfg->mel_dim, PD = cfg->postnet_dim;
     if (int rc = check_encoder_dims("acoustic model", D, V)) return rc;
-    if (H < 32 || H > 1024 || H % 32 != 0 || PN < 32 || PN % 32 != 0 || MEL < 4 || MEL > 128 || MEL % 4 != 0 || PD < 4 || PD > 1024 || PD % 4 != 0 || 2 * D + PN > 1024)
+    if (H < 32 || H > 1024 || H % 32 != 0 || PN < 32 || PN % 32 != 0 || MEL < 4 || MEL > 128 || MEL % 4 != 0 || PD < 4 || PD > 1024 || PD % 4 != 0 || 2 * D + PN > 1024 || (2 * D) % 32 != 0)
         return failf(VTTS_ERR_INVALID, "acoustic model: decoder_dim and prenet_dim must be multiples of 32 (matrix-core k-steps), decoder_dim <= 1024, "
                                        "2 * encoder_dim + prenet_dim <= 1024, mel_dim <= 128 and postnet_dim <= 1024 multiples of 4");
     auto* h = new (std::nothrow) vtts_nat_acoustic();
@@ -1110,10 +1136,37 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
                 for (int c = 0; c < cols; ++c) out[((size_t)(k >> 2) * cols + c) * 4 + (k & 3)] = W[(size_t)k * cols + c];
         });
     }
-    // decoder LSTM weights in the step kernel's order (add_lstm_mfma); layer 2's Haiku matrix is [x | h1 | h2] and the decoder
-    // STATE holds [h1 | x | h2], so its rows are permuted here
-    h->add_lstm_mfma("lstm/linear", X + H, H);
-    h->add_lstm_mfma("lstm_1/linear", X + H + H, H, [H, X](int zr) { return zr < H ? X + zr : (zr < H + X ? zr - H : zr); });
+    // decoder LSTM weights in the step kernel's order (add_lstm_mfma).  Haiku's matrices are [cond ; p ; h1] (layer 1) and
+    // [cond ; p ; h1 ; h2] (layer 2: hk.deep_rnn_with_skip_connections puts the network input first); the per-frame step multiplies
+    // the state rows [p ; h1] / [p ; h1 ; h2] = Haiku rows E + r, and the cond rows [0, E) go into the GEMM ahead of the loop:
+    // "#cond" = those rows as a one-tap convolution for nat_conv_mfma_k with the output columns in the step kernel's accumulator order
+    // c' = ((slice * 2 + lane / 32) * 4 + unit pair) * 4 + gate  <->  Haiku column gate * H + 8 * slice + 2 * (unit pair) + lane / 32,
+    // "#condb" = the bias in that order.
+    const int E = 2 * D;
+    h->add_lstm_mfma("lstm/linear", PN + H, H, [E](int zr) { return E + zr; });
+    h->add_lstm_mfma("lstm_1/linear", PN + H + H, H, [E](int zr) { return E + zr; });
+    for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
+        const std::string mod = l;
+        const int G4 = 4 * H, MB = G4 / 32, NCS = E / 32;
+        auto hcol = [H](int cp) {  // accumulator-order column -> Haiku column
+            const int gate = cp & 3, rq = (cp >> 2) & 3, lh = (cp >> 4) & 1, slice = cp >> 5;
+            return gate * H + 8 * slice + 2 * rq + lh;
+        };
+        h->add_extra(mod + "#cond", (size_t)MB * NCS * 64 * 16 * sizeof(float), [mod, E, G4, MB, NCS, hcol](const NatModel& m, float* out) {
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            for (int mb = 0; mb < MB; ++mb)
+                for (int cs = 0; cs < NCS; ++cs)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 16; ++e) {
+                            const int c = 32 * cs + 16 * (lane >> 5) + e, cp = 32 * mb + (lane & 31);
+                            out[(((size_t)mb * NCS + cs) * 64 + lane) * 16 + e] = W[(size_t)c * G4 + hcol(cp)];
+                        }
+        });
+        h->add_extra(mod + "#condb", (size_t)G4 * sizeof(float), [mod, G4, hcol](const NatModel& m, float* out) {
+            const std::vector<float>& bv = m.arrs[m.find(mod, "b")].host;
+            for (int cp = 0; cp < G4; ++cp) out[cp] = bv[hcol(cp)];
+        });
+    }
     h->layout();
     *out = h;
     return VTTS_OK;
@@ -1146,7 +1199,7 @@ VTTS_API int vtts_nat_acoustic_bind_packed(vtts_nat_acoustic* h, void* dev_blob,
     return h->bind(dev_blob, blob_bytes);
 }
 static size_t nat_dec_state_floats(const vtts_nat_acoustic_cfg& c, int B) {
-    const size_t Bp = (size_t)(B + 63) / 64 * 64, H = c.decoder_dim, ZW = 2 * H + 2 * (size_t)c.encoder_dim + c.prenet_dim;
+    const size_t Bp = (size_t)(B + 63) / 64 * 64, H = c.decoder_dim, ZW = 2 * H + c.prenet_dim;  // rows [p | h1 | h2]
     return (2 * ZW + 2 * H) * Bp;
 }
 VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lmax, int Fmax, size_t* bytes) {
@@ -1158,6 +1211,7 @@ VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B
              + align_up((size_t)B * Fmax * MEL * 4, 256)                                                   // decoder mel
              + 2 * align_up((size_t)B * Fmax * PD * 4, 256)                                                // postnet ping-pong
              + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256)                                          // decoder state Z[2], c1, c2
+             + 2 * align_up((size_t)B * Fmax * 4 * h->cfg.decoder_dim * 4, 256)                           // hoisted gate pre-activations G1, G2
              + align_up(nat_enc_lstm_floats((int)D, B, Lmax) * 4, 256);                                    // encoder LSTMs' scratch
     return VTTS_OK;
 }
@@ -1190,9 +1244,10 @@ VTTS_API int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint
                                                 void* stream) {
     return vtts_nat_acoustic_keep_masks_haiku_mode(h, rng_key0, rng_key1, 0, B, Fmax, keep_dev, stream);
 }
-VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
-                                       const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+// forward() and forward_groups(): ngroups = 0 is the plain call (the postnet on the caller's stream after the last frame)
+static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
+                            const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev, void* workspace,
+                            size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0, const int32_t* group_frames) {
     if (!h || !tokens_dev || !lengths_dev || !durations_dev || !nframes_dev || !mel_dev) return failf(VTTS_ERR_INVALID, "null argument");
     if (!h->blob) return failf(VTTS_ERR_STATE, "forward() before pack()/bind_packed()");
     size_t need = 0;
@@ -1200,9 +1255,32 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
     if (rc) return rc;
     if (!workspace || workspace_bytes < need) return failf(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
     if (Lmax > 2048) return failf(VTTS_ERR_INVALID, "at most 2048 tokens per sentence (upsampling weights live in LDS)");
+    h->groups_valid = 0;
+    if (ngroups > 0) {
+        if (!group_row0 || !group_frames) return failf(VTTS_ERR_INVALID, "null argument");
+        if (ngroups > 64) return failf(VTTS_ERR_INVALID, "at most 64 groups (got %d)", ngroups);
+        if (group_row0[0] != 0 || group_row0[ngroups] != B) return failf(VTTS_ERR_INVALID, "the groups must cover rows [0, %d)", B);
+        for (int g = 0; g < ngroups; ++g)
+            if (group_row0[g + 1] <= group_row0[g] || group_frames[g] < 1 || group_frames[g] > Fmax)
+                return failf(VTTS_ERR_INVALID, "group %d: rows [%d, %d), %d frames (every group needs at least one row and 1 <= frames <= Fmax = %d)", g,
+                             group_row0[g], group_row0[g + 1], group_frames[g], Fmax);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int D = h->cfg.encoder_dim, V = h->cfg.vocab_size, H = h->cfg.decoder_dim, PN = h->cfg.prenet_dim, MEL = h->cfg.mel_dim, PD = h->cfg.postnet_dim;
-    const int E = 2 * D;
+    const int E = 2 * D, G4 = 4 * H;
+    // the side stream and the events of the hand-over (created once per handle, on the device the caller made current)
+    if (!h->side) {
+        HIP_TRYN(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIP_TRYN(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIP_TRYN(hipEventCreateWithFlags(&h->ev_gates, hipEventDisableTiming));
+    }
+    while ((int)h->ev_dec.size() < ngroups) {
+        hipEvent_t a, b;
+        HIP_TRYN(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRYN(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        h->ev_dec.push_back(a);
+        h->ev_done.push_back(b);
+    }
     char* p = static_cast<char*>(workspace);
     auto take = [&](size_t bytes) {
         float* r = reinterpret_cast<float*>(p);
@@ -1217,64 +1295,123 @@ VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* toke
     float* pA = take((size_t)B * Fmax * PD * 4);
     float* pB = take((size_t)B * Fmax * PD * 4);
     float* dstate = take(nat_dec_state_floats(h->cfg, B) * 4);
+    float* G1 = take((size_t)B * Fmax * G4 * 4);
+    float* G2 = take((size_t)B * Fmax * G4 * 4);
     float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);
     rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);  // model.py:131
     if (rc) return rc;
     hipLaunchKernelGGL(nat_upsample_k, dim3(Fmax, B), dim3(256), (2 * Lmax + 8) * sizeof(float), s, enc, lengths_dev, durations_dev, nframes_dev, cond,
                        Lmax, Fmax, E);  // :132
+    HIP_TRYN(hipMemsetAsync(mel_dev, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame
+    // postnet (:113-121) + residual (:151) of rows [r0, r1) over their first `frames` frames: 4 x (Conv1D(PD, 5) + BatchNorm + tanh),
+    // Conv1D(MEL, 5), mel + .   A row's result does not depend on the launch it is part of.
+    auto postnet = [&](int r0, int r1, int frames, hipStream_t ps) {
+        const float* cur = mel0 + (size_t)r0 * Fmax * MEL;
+        float* bufs[2] = {pA + (size_t)r0 * Fmax * PD, pB + (size_t)r0 * Fmax * PD};
+        for (int i = 0; i < 5; ++i) {
+            const std::string sfx = i ? "_" + std::to_string(i) : "";
+            const std::string cv = "conv1_d" + sfx, bn = "batch_norm" + sfx;
+            const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD, MB = (cout + 31) / 32;
+            float* dst = i == 4 ? mel_dev + (size_t)r0 * Fmax * MEL : bufs[i & 1];
+            const float4* wpk = reinterpret_cast<const float4*>(h->extra(cv + "#mfma"));
+            const float *iv = i < 4 ? h->inv(bn) : nullptr, *mv = i < 4 ? h->dev(bn + "/~/mean_ema", "average") : nullptr, *ov = i < 4 ? h->dev(bn, "offset") : nullptr;
+            const int act = i < 4 ? (int)NAT_ACT_TANH : (int)NAT_ACT_NONE;
+            const float* res = i == 4 ? mel0 + (size_t)r0 * Fmax * MEL : nullptr;
+            if (MB >= 8)
+                hipLaunchKernelGGL((nat_conv_mfma_k<5, 2>), dim3((frames + 63) / 64, (MB + 7) / 8, r1 - r0), dim3(256), 0, ps, cur, nframes_dev + r0, wpk,
+                                   h->dev(cv, "b"), iv, mv, ov, res, dst, Fmax, cin, cout, act, 0);
+            else
+                hipLaunchKernelGGL((nat_conv_mfma_k<5, 1>), dim3((frames + 63) / 64, (MB + 3) / 4, r1 - r0), dim3(256), 0, ps, cur, nframes_dev + r0, wpk,
+                                   h->dev(cv, "b"), iv, mv, ov, res, dst, Fmax, cin, cout, act, 0);
+            cur = dst;
+        }
+    };
     {  // autoregressive decoder (:134-150): per frame LSTM1, LSTM2, projection + next frame's prenet, all sentences at once
-        const int Bp = (B + 63) / 64 * 64, X = E + PN, ZW = 2 * H + X;
+        const int Bp = (B + 63) / 64 * 64, ZW = PN + 2 * H;
         float* Z[2] = {dstate, dstate + (size_t)ZW * Bp};
         float* c1 = dstate + 2 * (size_t)ZW * Bp;
         float* c2 = c1 + (size_t)H * Bp;
-        HIP_TRYN(hipMemsetAsync(dstate, 0, nat_dec_state_floats(h->cfg, B) * 4, s));
+        HIP_TRYN(hipMemsetAsync(dstate, 0, nat_dec_state_floats(h->cfg, B) * 4, s));  // frame 0: h1 = h2 = 0, c = 0, prenet(0) = 0 (no biases)
         HIP_TRYN(hipMemsetAsync(mel0, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame stay zero
-        hipLaunchKernelGGL(nat_dec_init_k, dim3(B), dim3(256), 0, s, cond, Z[0] + (size_t)H * Bp, B, Bp, Fmax, E);
+        // the conditioning's share of both layers' gates for every frame: tiles [0, 1) of 64 frames here, the rest beside the first 64 steps
+        const int tiles = (Fmax + 63) / 64, MBG = G4 / 32;
+        auto gates = [&](int tile0, int ntiles, hipStream_t gs) {
+            hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3(ntiles, (MBG + 7) / 8, B), dim3(256), 0, gs, cond, nframes_dev,
+                               reinterpret_cast<const float4*>(h->extra("lstm/linear#cond")), h->extra("lstm/linear#condb"), nullptr, nullptr, nullptr, nullptr, G1,
+                               Fmax, E, G4, (int)NAT_ACT_NONE, tile0);
+            hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3(ntiles, (MBG + 7) / 8, B), dim3(256), 0, gs, cond, nframes_dev,
+                               reinterpret_cast<const float4*>(h->extra("lstm_1/linear#cond")), h->extra("lstm_1/linear#condb"), nullptr, nullptr, nullptr, nullptr, G2,
+                               Fmax, E, G4, (int)NAT_ACT_NONE, tile0);
+        };
+        gates(0, 1, s);
+        if (tiles > 1) {
+            HIP_TRYN(hipEventRecord(h->ev_fork, s));
+            HIP_TRYN(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+            gates(1, tiles - 1, h->side);
+            HIP_TRYN(hipEventRecord(h->ev_gates, h->side));
+        }
         const float4* w1 = reinterpret_cast<const float4*>(h->extra("lstm/linear#mfma"));
         const float4* w2 = reinterpret_cast<const float4*>(h->extra("lstm_1/linear#mfma"));
-        const float *b1 = h->dev("lstm/linear", "b"), *b2 = h->dev("lstm_1/linear", "b");
         const float4* f1 = reinterpret_cast<const float4*>(h->extra("linear_1#k4"));
         const float4* f2 = reinterpret_cast<const float4*>(h->extra("linear_2#k4"));
         const float4* wp = reinterpret_cast<const float4*>(h->extra("linear#k4"));
         const float* bp = h->dev("linear", "b");
         const bool wide = B > 32;  // two 32-sentence tiles per wave once there are that many sentences
         const dim3 lgrid(H / 8, wide ? Bp / 64 : 1);
-        auto lstm = [&](const float* inA, int KA, const float* inB, const float4* w, const float* bias, float* cst, float* hout, int f) {
-            const NatLstmOps o{inA, inB, w, bias, cst, hout};
+        auto lstm = [&](const float* inA, int KA, const float* inB, const float4* w, const float* gin, float* cst, float* hout, int f) {
+            const NatLstmOps o{inA, inB, w, nullptr, cst, hout, gin + (size_t)f * G4, (size_t)Fmax * G4};
             if (wide) hipLaunchKernelGGL((nat_dec_lstm_k<2, 8>), lgrid, dim3(512), 0, s, o, o, KA, H, nframes_dev, f, B, Bp, H);
             else hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, o, o, KA, H, nframes_dev, f, B, Bp, H);
         };
         const size_t plds = ((size_t)2 * H + 1024 + MEL + PN) * sizeof(float4);
         for (int f = 0; f < Fmax; ++f) {
+            if (f == 64) HIP_TRYN(hipStreamWaitEvent(s, h->ev_gates, 0));
             float* zc = Z[f & 1];
             float* zp = Z[(f + 1) & 1];
-            lstm(zc + (size_t)H * Bp, X, zp, w1, b1, c1, zc, f);
-            lstm(zc, H + X, zp + (size_t)(H + X) * Bp, w2, b2, c2, zc + (size_t)(H + X) * Bp, f);
-            hipLaunchKernelGGL(nat_dec_proj_prenet_k, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, cond, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f,
-                               B, Bp, Fmax, E, PN, H, MEL);
+            lstm(zc, PN, zp + (size_t)PN * Bp, w1, G1, c1, zc + (size_t)PN * Bp, f);
+            lstm(zc, PN + H, zp + (size_t)(PN + H) * Bp, w2, G2, c2, zc + (size_t)(PN + H) * Bp, f);
+            hipLaunchKernelGGL(nat_dec_proj_prenet_k, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f, B, Bp,
+                               Fmax, PN, H, MEL);
+            // a group whose last frame this was: its postnet starts now, on the side stream, under the remaining decoder steps
+            for (int g = 0; g < ngroups; ++g) {
+                if (group_frames[g] != f + 1) continue;
+                HIP_TRYN(hipEventRecord(h->ev_dec[g], s));
+                HIP_TRYN(hipStreamWaitEvent(h->side, h->ev_dec[g], 0));
+                postnet(group_row0[g], group_row0[g + 1], group_frames[g], h->side);
+                HIP_TRYN(hipEventRecord(h->ev_done[g], h->side));
+            }
         }
     }
-    // postnet (:113-121) + residual (:151): 4 x (Conv1D(PD, 5) + BatchNorm + tanh), Conv1D(MEL, 5), mel + .
-    HIP_TRYN(hipMemsetAsync(mel_dev, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame
-    const float* cur = mel0;
-    float* bufs[2] = {pA, pB};
-    for (int i = 0; i < 5; ++i) {
-        const std::string sfx = i ? "_" + std::to_string(i) : "";
-        const std::string cv = "conv1_d" + sfx, bn = "batch_norm" + sfx;
-        const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD, MB = (cout + 31) / 32;
-        float* dst = i == 4 ? mel_dev : bufs[i & 1];
-        const float4* wpk = reinterpret_cast<const float4*>(h->extra(cv + "#mfma"));
-        const float *iv = i < 4 ? h->inv(bn) : nullptr, *mv = i < 4 ? h->dev(bn + "/~/mean_ema", "average") : nullptr, *ov = i < 4 ? h->dev(bn, "offset") : nullptr;
-        const int act = i < 4 ? (int)NAT_ACT_TANH : (int)NAT_ACT_NONE;
-        if (MB >= 8)
-            hipLaunchKernelGGL((nat_conv_mfma_k<5, 2>), dim3((Fmax + 63) / 64, (MB + 7) / 8, B), dim3(256), 0, s, cur, nframes_dev, wpk, h->dev(cv, "b"), iv, mv,
-                               ov, i == 4 ? mel0 : nullptr, dst, Fmax, cin, cout, act);
-        else
-            hipLaunchKernelGGL((nat_conv_mfma_k<5, 1>), dim3((Fmax + 63) / 64, (MB + 3) / 4, B), dim3(256), 0, s, cur, nframes_dev, wpk, h->dev(cv, "b"), iv, mv,
-                               ov, i == 4 ? mel0 : nullptr, dst, Fmax, cin, cout, act);
-        cur = dst;
+    if (ngroups > 0) {
+        for (int g = 0; g < ngroups; ++g) HIP_TRYN(hipStreamWaitEvent(s, h->ev_done[g], 0));  // stream order for the caller: mel_dev is complete after this call on `s`
+        h->groups_valid = ngroups;
+    } else {
+        postnet(0, B, Fmax, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return failf(VTTS_ERR_HIP, "acoustic model launch failed: %s", hipGetErrorString(e));
+    return VTTS_OK;
+}
+
+VTTS_API int vtts_nat_acoustic_forward(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
+                                       const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return nat_acoustic_run(h, tokens_dev, lengths_dev, durations_dev, nframes_dev, B, Lmax, Fmax, keep_dev, mel_dev, workspace, workspace_bytes, stream, 0,
+                            nullptr, nullptr);
+}
+
+VTTS_API int vtts_nat_acoustic_forward_groups(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
+                                              const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,
+                                              void* workspace, size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0,
+                                              const int32_t* group_frames) {
+    if (ngroups < 1) return failf(VTTS_ERR_INVALID, "forward_groups() needs at least one group (got %d)", ngroups);
+    return nat_acoustic_run(h, tokens_dev, lengths_dev, durations_dev, nframes_dev, B, Lmax, Fmax, keep_dev, mel_dev, workspace, workspace_bytes, stream,
+                            ngroups, group_row0, group_frames);
+}
+
+VTTS_API int vtts_nat_acoustic_wait_group(vtts_nat_acoustic* h, int group, void* stream) {
+    if (!h) return failf(VTTS_ERR_INVALID, "null argument");
+    if (group < 0 || group >= h->groups_valid) return failf(VTTS_ERR_STATE, "wait_group(%d): the last forward_groups() call had %d groups", group, h->groups_valid);
+    HIP_TRYN(hipStreamWaitEvent(static_cast<hipStream_t>(stream), h->ev_done[group], 0));
     return VTTS_OK;
 }

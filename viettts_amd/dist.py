@@ -114,12 +114,42 @@ def broadcast_packed_weights(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     return blob
 
 
+def blob_checksum(blob: torch.Tensor) -> int:
+    """A 64-bit checksum of a packed weight blob (uint8 tensor), computed where the blob lives: sum over the 8-byte words of
+    ``word * (2 * index + 1)`` modulo 2^64 — position-weighted, so swapped or shifted words change it as well as flipped bits."""
+    b = blob.reshape(-1)
+    pad = (-b.numel()) % 8
+    if pad:
+        b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
+    w = b.view(torch.int64)
+    k = torch.arange(w.numel(), dtype=torch.int64, device=w.device) * 2 + 1
+    return int((w * k).sum().item())  # int64 arithmetic wraps modulo 2^64
+
+
+def verify_blob_on_all_ranks(blob: torch.Tensor, what: str = "packed weights") -> int:
+    """After the start-up broadcast: every rank checksums the blob it holds, the checksums are all-reduced with MIN and MAX, and
+    every rank fails fast if they differ — a rank that computed on a damaged copy of the weights would otherwise produce
+    plausible-looking audio forever.  A start-up collective (two 8-byte all-reduces per model), not a data-path one.
+    Returns the checksum."""
+    cs = blob_checksum(blob)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        lo = torch.tensor([cs], dtype=torch.int64, device=blob.device)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if int(lo.item()) != int(hi.item()):
+            raise RuntimeError(f"{what}: the ranks hold different blobs after the start-up broadcast (this rank's checksum {cs & 0xFFFFFFFFFFFFFFFF:#018x}; "
+                               f"min {int(lo.item()) & 0xFFFFFFFFFFFFFFFF:#018x}, max {int(hi.item()) & 0xFFFFFFFFFFFFFFFF:#018x} over {dist.get_world_size()} ranks)")
+    return cs
+
+
 def setup_model_dp(model, load_fn, info: Optional[RankInfo] = None, stats: Optional[dict] = None):
     """Rank 0 loads + packs the weights (``load_fn(model)`` calls its ``load_params`` and runs on rank 0 only), every other
     rank receives the packed blob: ONE broadcast per model at start-up (HiFi-GAN generator 27.9 MB bf16 / 55.7 MB fp32,
     NAT duration model, NAT acoustic model).  ``model`` offers ``packed_bytes``, ``packed_blob()``, ``adopt_packed(blob)``
     and ``device`` (Generator, DurationModel, AcousticModel).  ``stats`` (a dict) receives ``bytes``, ``broadcast_ms`` (device-
-    synchronised wall time of the one collective on this rank), ``backend`` and ``world`` as the process group reports them."""
+    synchronised wall time of the one collective on this rank), ``backend`` and ``world`` as the process group reports them, and
+    ``blob_checksum`` / ``blob_checksum_equal`` (:func:`verify_blob_on_all_ranks`: the job stops here if a rank's copy differs)."""
     import time
 
     info = info or rank_info()
@@ -139,8 +169,13 @@ def setup_model_dp(model, load_fn, info: Optional[RankInfo] = None, stats: Optio
             torch.cuda.synchronize(blob.device)
         if stats is not None:
             stats.update(broadcast_ms=(time.perf_counter() - t0) * 1e3, backend=dist.get_backend(), world=dist.get_world_size())
+        cs = verify_blob_on_all_ranks(blob, type(model).__name__ + " weights")  # raises on every rank if any rank's copy differs
+        if stats is not None:
+            stats.update(blob_checksum=f"{cs & 0xFFFFFFFFFFFFFFFF:#018x}", blob_checksum_equal=True)
         if info.rank != 0:
             model.adopt_packed(blob)
+    elif stats is not None:
+        stats.update(blob_checksum=f"{blob_checksum(blob) & 0xFFFFFFFFFFFFFFFF:#018x}", blob_checksum_equal=None)  # one rank: nothing to compare
     return model
 
 

@@ -126,8 +126,7 @@ class Generator:
     # ---- options --------------------------------------------------------------------------------
     def set_option(self, name: str, value: int) -> None:
         _lib.check(self.lib, self.lib.vtts_hifigan_set_option(self._h, name.encode(), int(value)))
-        if name in ("microbatch", "streams", "chains"):
-            self._ws = None
+        # the cached workspace stays: _workspace() asks the engine for the size every call and only ever grows it
 
     def get_option(self, name: str) -> int:
         v = C.c_int64(0)

@@ -41,7 +41,9 @@ def _log_stream_once(partitionable: bool) -> None:
     is installed; the reference pins no version): said once, so that a mel that differs from a JAX >= 0.5 run is not a silent surprise."""
     if partitionable not in _STREAM_LOGGED:
         _STREAM_LOGGED.add(partitionable)
-        logging.getLogger("viettts_amd.nat").info(
+        # WARNING, not INFO: invisible at the default log level, a mel that differs from a run of the reference under another JAX release
+        # would be a silent surprise (ADVICE r03)
+        logging.getLogger("viettts_amd.nat").warning(
             "prenet dropout masks: jax.random threefry, %s layout, under dm-haiku's PRNGSequence key chain (set VTTS_JAX_THREEFRY_PARTITIONABLE=%d for the other one)",
             "partitionable (JAX >= 0.5 default; unpinned restatement)" if partitionable else "classic (JAX < 0.5 default)", 0 if partitionable else 1)
 
@@ -150,14 +152,23 @@ class AcousticModel:
                                                                                   _ptr(keep), C.c_void_p(stream.cuda_stream)))
         return keep
 
+    def wait_group(self, group: int, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """Make ``stream`` (default: torch's current stream) wait until the rows of ``group`` of the last ``group_row0`` call are complete."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_wait_group(self._h, int(group), C.c_void_p(st.cuda_stream)))
+
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
                  keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None, to_host: bool = True,
-                 dropout_rng=None):
+                 dropout_rng=None, group_row0: Optional[Sequence[int]] = None):
         """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``.
         Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_rng`` (the checkpoint's jax PRNGKey, uint32[2]: the
         reference's own mask stream, drawn on the GPU), or ``dropout_seeds`` (one int per sentence: this library's own
         per-sentence streams, drawn on the GPU), or none of them (no dropout).  ``to_host=False`` returns the device tensor ``[B, Fmax, mel_dim]`` (rows past a
-        sentence's ``n_frames`` are zero) instead of per-sentence host arrays: the generator's input stays in HBM."""
+        sentence's ``n_frames`` are zero) instead of per-sentence host arrays: the generator's input stays in HBM.
+        ``group_row0`` (with ``to_host=False``): row boundaries ``[0, ..., B]`` of groups whose mel is handed over as soon as the decoder has
+        produced the group's last frame (include/vtts_nat.h: vtts_nat_acoustic_forward_groups); a consumer stream waits for group g with
+        :meth:`wait_group`.  Same mel, bit for bit."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
         B = len(sentences)
@@ -193,11 +204,24 @@ class AcousticModel:
             self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
-            _lib.check(
-                self.lib,
-                self.lib.vtts_nat_acoustic_forward(self._h, _ptr(tok_d), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d), _ptr(out),
-                                                   _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream)),
-            )
+            if group_row0 is not None:
+                if to_host:
+                    raise ValueError("group_row0 hands the mel over on the device: use to_host=False")
+                r0 = [int(v) for v in group_row0]
+                ng = len(r0) - 1
+                gfr = [max(int(n) for n in n_frames[r0[g] : r0[g + 1]]) if r0[g + 1] > r0[g] else 0 for g in range(ng)]
+                _lib.check(
+                    self.lib,
+                    self.lib.vtts_nat_acoustic_forward_groups(self._h, _ptr(tok_d), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d), _ptr(out),
+                                                              _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream), ng,
+                                                              (C.c_int32 * (ng + 1))(*r0), (C.c_int32 * ng)(*gfr)),
+                )
+            else:
+                _lib.check(
+                    self.lib,
+                    self.lib.vtts_nat_acoustic_forward(self._h, _ptr(tok_d), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d), _ptr(out),
+                                                       _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream)),
+                )
         if not to_host:
             return out
         host = out.cpu().numpy()

@@ -7,7 +7,8 @@ and keeps its waveforms.  The only collectives of the whole job are the three st
 (viettts_amd/dist.py).  Within a rank the stages run batched:
     tokens --DurationModel--> seconds/token --rules (text2mel.py:90-97)--> frames --AcousticModel--> mel --Generator--> wav
 with the generator fed ragged batches (sentences sorted by length, each batch padded to its longest; the bf16 engine
-gives every utterance the zero padding it would see alone and skips the tiles past its end).
+gives every utterance the zero padding it would see alone and skips the tiles past its end), and the last two stages
+overlapped: the acoustic model hands its mel over in groups as the decoder finishes them (synthesize_sentences).
 """
 from __future__ import annotations
 
@@ -28,7 +29,10 @@ def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: in
     """Cut ``rows`` (sorted by ascending ``frames``) into the generator's ragged batches.  gen_batch > 0: at most that many sentences
     per batch.  gen_batch = 0: as few passes as PASS_FRAMES of REAL frames each allow (the ragged kernels skip the tiles past an
     utterance's end, so padding costs workspace, not time), the passes balanced by frames: 256 transcript sentences (54.7k frames,
-    longest 281) are ONE pass instead of four of 64 sentences — fewer, larger launches (generator stage 38.1 -> 34 ms)."""
+    longest 281) are ONE pass instead of four of 64 sentences — fewer, larger launches (generator stage 38.1 -> 34 ms).
+    Padding does cost WORKSPACE (4 buffers x 8192 x 2 B per padded frame): a batch is also closed before its padded size,
+    ``len(batch) x longest``, would pass 2 x PASS_FRAMES — 500 sentences of 100 frames and one of 1000 are two passes, not one of
+    500 000 padded frames (32 GB)."""
     rows = list(rows)
     if not rows:
         return []
@@ -38,25 +42,70 @@ def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: in
     k = max(1, -(-total // int(pass_frames * 1.25)))
     out, acc, cut = [[]], 0, 1
     for r, f in zip(rows, frames):
-        if acc >= total * cut / k and cut < k and out[-1]:
+        if out[-1] and ((acc >= total * cut / k and cut < k) or (len(out[-1]) + 1) * int(f) > 2 * pass_frames):
+            if acc >= total * cut / k and cut < k:
+                cut += 1
             out.append([])
-            cut += 1
         out[-1].append(r)
         acc += int(f)
     return out
 
 
+def _overlap_groups(frames_desc: Sequence[int], ngroups: int) -> List[int]:
+    """Row boundaries ``[0, ..., n]`` of ``ngroups`` contiguous groups of a list of frame counts sorted in DESCENDING order, the groups
+    balanced by frames (the last group — the shortest sentences — is the first whose mel the decoder completes)."""
+    n = len(frames_desc)
+    ngroups = max(1, min(int(ngroups), n))
+    total = float(sum(frames_desc))
+    bounds, acc = [0], 0.0
+    for i, f in enumerate(frames_desc):
+        acc += f
+        if len(bounds) < ngroups and acc >= total * len(bounds) / ngroups and i + 1 < n and n - (i + 1) >= ngroups - len(bounds):
+            bounds.append(i + 1)
+    while len(bounds) < ngroups:  # degenerate inputs (many zero-frame rows): fall back to fewer groups
+        ngroups -= 1
+    bounds.append(n)
+    return bounds
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(device: torch.device):
+    """(acoustic stream — high priority: its per-frame launches are short and latency-bound, and must not queue behind the generator's
+    thousands of workgroups —, copy stream) of a device, created once."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device, priority=-1), torch.cuda.Stream(device=device))
+    return _SIDE_STREAMS[key]
+
+
+OVERLAP_MIN_FRAMES = 16384  # below this a rank's shard is one small generator pass: nothing worth overlapping
+OVERLAP_GROUPS = 4
+
+
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
                          dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 0,
-                         timing: Optional[dict] = None) -> Dict[int, np.ndarray]:
+                         timing: Optional[dict] = None, overlap_groups: Optional[int] = None) -> Dict[int, np.ndarray]:
     """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index.  ``timing`` (a dict) receives
-    device-synchronised wall seconds per stage."""
+    wall seconds per stage.
+
+    **The acoustic model and the generator overlap (round 4).**  The decoder is a chain of ``max(frames)`` dependent steps of three short
+    launches each (latency-bound; it uses a fraction of the chip), the generator a few dozen chip-filling launches (power-bound).  The
+    sentences, sorted longest first, are cut into ``overlap_groups`` contiguous groups balanced by frames; the acoustic model runs on a
+    high-priority stream of its own and hands a group's mel over as soon as the decoder has produced the group's last frame
+    (include/vtts_nat.h: vtts_nat_acoustic_forward_groups — the postnet of that group on a side stream), and the generator consumes
+    the groups shortest first on the caller's stream, each group's waveforms leaving for pinned host memory on a copy stream as soon as
+    its pass ends.  Masks are seeded by the GLOBAL sentence index and every stage computes a row independently of its batch, so the
+    samples do not depend on the grouping (tests/test_gpu_nat.py).  ``overlap_groups``: None = by size (1 below OVERLAP_MIN_FRAMES
+    frames, else OVERLAP_GROUPS), 1 = the stages one after the other."""
     import time
 
-    def mark(name, t_prev):
+    def mark(name, t_prev, sync=True):
         if timing is None:
             return t_prev
-        torch.cuda.synchronize()
+        if sync:
+            torch.cuda.synchronize()
         now = time.perf_counter()
         timing[name] = timing.get(name, 0.0) + now - t_prev
         return now
@@ -79,37 +128,61 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     wavs: Dict[int, np.ndarray] = {}
     gfr = {k: nfr[k] - trail[k] for k in ok}  # frames the generator sees: the mel minus its trailing silence (:102)
     if ok:
+        dev = generator.device
+        ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
+        total_frames = int(sum(gfr.values()))
+        if overlap_groups is None:
+            overlap_groups = OVERLAP_GROUPS if (ragged and total_frames >= OVERLAP_MIN_FRAMES) else 1
+        bounds = _overlap_groups([nfr[k] for k in ok], overlap_groups if hasattr(acoustic_model, "wait_group") else 1)
+        ngroups = len(bounds) - 1
+        cur = torch.cuda.current_stream(dev)
+        s_ac, s_copy = _side_streams(dev)
+        ev_ac_end = torch.cuda.Event(enable_timing=False)
         # prenet dropout (on at inference, model.py:95-100): masks drawn on the GPU, seeded by the sentence's GLOBAL index.
         # The mel stays in HBM: [len(ok), Fmax, 80] on the device, rows past a sentence's frames zero.
-        mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok],
-                                 dropout_seeds=None if dropout_seed is None else [dropout_seed + mine[k] for k in ok], to_host=False)
-        t_last = mark("acoustic_s", t_last)
+        seeds = None if dropout_seed is None else [dropout_seed + mine[k] for k in ok]
+        if ngroups > 1:
+            s_ac.wait_stream(cur)
+            with torch.cuda.stream(s_ac):
+                mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False,
+                                         group_row0=bounds)
+                ev_ac_end.record(s_ac)
+            mel_dev.record_stream(cur)
+            t_last = mark("acoustic_enqueue_s", t_last, sync=False)
+        else:
+            mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False)
+            t_last = mark("acoustic_s", t_last)
         # the generator takes ragged batches (vtts_hifigan_forward_ragged: each utterance's samples are those of running it
-        # alone): sentences sorted by length, dealt into batches of at most `gen_batch`, cut to the batch's longest
-        ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
-        todo = sorted((r for r, k in enumerate(ok) if gfr[k] > 0), key=lambda r: gfr[ok[r]])
+        # alone): a group's sentences sorted by length, cut into passes by _generator_batches, each cut to its longest
         pending = []
-        for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, _pass_frames(generator)):
-            fr = [gfr[ok[r]] for r in rows]
-            batch = mel_dev[torch.tensor(rows, device=mel_dev.device), : max(fr)].contiguous()  # a device-side gather (plumbing)
-            if ragged:
-                prev = generator.get_option("microbatch")
-                if prev == 0:
-                    generator.set_option("microbatch", len(rows))  # one pass for the batch (the engine's own cut is PASS_FRAMES of PADDED frames)
-                try:
-                    w = generator.forward_ragged(batch, fr)
-                finally:
-                    generator.set_option("microbatch", prev)  # a caller's own setting is left alone
-            else:
-                w = generator(batch)
-            host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
-            host.copy_(w, non_blocking=True)  # pinned, stream-ordered: the next batch computes behind this copy's enqueue
-            pending.append((rows, fr, host))
+        pf = _pass_frames(generator)
+        for g in range(ngroups - 1, -1, -1):  # the shortest sentences' group is complete first
+            if ngroups > 1:
+                acoustic_model.wait_group(g, cur)
+            todo = sorted((r for r in range(bounds[g], bounds[g + 1]) if gfr[ok[r]] > 0), key=lambda r: gfr[ok[r]])
+            for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, pf):
+                fr = [gfr[ok[r]] for r in rows]
+                batch = mel_dev[torch.tensor(rows, device=dev), : max(fr)].contiguous()  # a device-side gather (plumbing)
+                w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
+                # pinned, on a copy stream: the next pass computes while this one's samples leave
+                done = torch.cuda.Event()
+                done.record(cur)
+                host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
+                s_copy.wait_event(done)
+                with torch.cuda.stream(s_copy):
+                    host.copy_(w, non_blocking=True)
+                w.record_stream(s_copy)
+                pending.append((rows, fr, host))
+        if ngroups > 1:
+            cur.wait_stream(s_ac)
+        cur.wait_stream(s_copy)
         torch.cuda.synchronize()
         for rows, fr, host in pending:
             hn = host.numpy()
             for q, r in enumerate(rows):
                 wavs[mine[ok[r]]] = hn[q, : generator.hop * fr[q]]  # a view of the batch's pinned buffer (kept alive by the view)
+        if timing is not None:
+            timing["overlap_groups"] = ngroups
     else:
         t_last = mark("acoustic_s", t_last)
     t_last = mark("generator_s", t_last)
