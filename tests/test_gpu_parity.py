@@ -86,6 +86,64 @@ def test_resblock_conv_kat(gen_v1, v1_params, dev, spec, kernels):
     assert err < TIGHT, f"{spec.key} ({'generic' if kernels else 'mfma'}): max|err| = {err}"
 
 
+def _pair_cases_f32():
+    seen, out = set(), []
+    specs = conv_specs(V1)
+    for i, s in enumerate(specs):
+        if s.kind == "conv" and s.cin == s.cout and s.cin <= 128 and "convs1_" in s.key:
+            sig = (s.cin, s.k, s.dilation)
+            if sig not in seen:
+                seen.add(sig)
+                out.append((s, specs[i + 1]))
+    return out
+
+
+@pytest.mark.parametrize("pair", _pair_cases_f32(), ids=lambda p: f"C{p[0].cin}k{p[0].k}d{p[0].dilation}")
+def test_fp32_fused_pair_kat(gen_v1, v1_params, dev, pair):
+    """The fused fp32 pair kernel (kernels_f32_pair.hip) on every (C, k, rate) it covers against the oracle's
+    ``c2(lrelu(c1(lrelu(x)))) + x`` (vietTTS/hifigan/model.py:45-50) in fp64, lengths that are no multiple of any tile (ragged first /
+    last tiles, several tiles per utterance), AND bit for bit against the two separate convolution launches."""
+    c1, c2 = pair
+    assert c2.key == c1.key.replace("convs1_", "convs2_") and c2.dilation == 1
+    rng = np.random.default_rng(c1.cin * 1000 + c1.k * 10 + c1.dilation)
+    B, L = 2, 300 if c1.cin >= 128 else 1000
+    x = rng.standard_normal((B, c1.cin, L)).astype(np.float32) * 2.0
+    xn = _nwc(x).astype(np.float64)
+    w1, b1 = v1_params[c1.key]["w"].astype(np.float64), v1_params[c1.key]["b"].astype(np.float64)
+    w2, b2 = v1_params[c2.key]["w"].astype(np.float64), v1_params[c2.key]["b"].astype(np.float64)
+    xt = orc.conv1d(orc.leaky_relu(xn, 0.1), w1, b1, c1.dilation, orc.get_padding(c1.k, c1.dilation))
+    ref = orc.conv1d(orc.leaky_relu(xt, 0.1), w2, b2, 1, orc.get_padding(c2.k, 1)) + xn
+    xd = torch.from_numpy(x).to(dev)
+    y = gen_v1.run_pair(c1.key, xd)
+    torch.cuda.synchronize()
+    err = np.abs(_nwc(y.cpu().numpy()) - ref).max()
+    assert err < TIGHT, f"{c1.key}: max|err| = {err}"
+    # the same fmaf chains in the same order as the two launches: the same bits
+    t = gen_v1.run_module(c1.key, xd, 0.1)
+    two = gen_v1.run_module(c2.key, t, 0.1, xd)
+    torch.cuda.synchronize()
+    assert torch.equal(two, y), float((two - y).abs().max())
+    with pytest.raises(Exception):
+        gen_v1.run_pair(c2.key, xd)  # not the first convolution of a pair
+
+
+@pytest.mark.parametrize("BT", [(1, 1), (2, 5), (1, 37), (3, 160)], ids=lambda v: f"B{v[0]}T{v[1]}")
+def test_fp32_fused_pairs_are_bit_identical(gen_v1, dev, BT):
+    """Whole generator, fp32 engine: fused pairs at C <= 64 (the default, option fuse = 2), at C <= 128 (fuse = 3) and one launch per
+    convolution (fuse = 0) give the SAME samples, bit for bit — so every golden / oracle test of the fp32 engine covers the fused path."""
+    B, T = BT
+    mel = torch.from_numpy(synthetic_mel(B, T, 31 + T)).to(dev)
+    outs = {}
+    try:
+        for fuse in (0, 2, 3, 1):
+            gen_v1.set_option("fuse", fuse)
+            outs[fuse] = gen_v1(mel).clone()
+    finally:
+        gen_v1.set_option("fuse", 2)
+    for fuse in (2, 3, 1):
+        assert torch.equal(outs[fuse], outs[0]), (fuse, float((outs[fuse] - outs[0]).abs().max()))
+
+
 def test_residual_in_place(gen_v1, v1_params, dev):
     """The engine writes c2(xt)+x over x for the 2nd/3rd pair of a ResBlock (res aliases y)."""
     spec = [s for s in conv_specs(V1) if s.cin == 64 and s.k == 7 and s.dilation == 1][0]

@@ -426,6 +426,46 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
 }
 
 
+// fp32 fused pair: c1 = convs1_z (rate d), c2 = convs2_z (rate 1): x [B][C][L] -> out, with the accumulate mode of the unfused c2 launch
+bool pair_f32_wanted(const vtts_hifigan* h, const Layer& c1, const Layer& c2, int L) {
+    if (h->opt_kernels != 0 || h->opt_fuse < 1 || !c1.has_wp || !c2.has_wp) return false;
+    if (c1.cin != c1.cout || c2.cin != c1.cin || c2.cout != c1.cin || c2.k != c1.k || c2.dil != 1) return false;
+    if (!pair_f32_supported(c1.cin, c1.k, c1.dil, L)) return false;
+    // fuse = 1, 2: the narrow stages (C <= 64), where the separate convolutions are bound by their memory phases (profiles/r03_g_f32_pmc.md:
+    // MfmaUtil 0.36-0.71 at 1.3-3 TB/s); fuse = 3: C = 128 too (there the halo columns a fused pair recomputes cost about what the saved
+    // traffic gains)
+    return c1.cin <= 64 || h->opt_fuse >= 3;
+}
+
+int run_pair_f32(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float* x, int B, int L, float* y, int acc_mode, float div, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_sb = (long)c1.cin * L;
+    a.x_sc = L;
+    a.x_st = 1;
+    a.wp = h->blob + c1.off_wp;
+    a.bias = reinterpret_cast<const float*>(h->blob + c1.off_b);
+    a.res = x;  // x = xt + x (model.py:50)
+    a.y = y;
+    a.B = B;
+    a.Cin = c1.cin;
+    a.Cout = c1.cout;
+    a.K = c1.k;
+    a.dil = c1.dil;
+    a.pad = c1.pad;
+    a.stride = 1;
+    a.L = L;
+    a.Lout = L;
+    a.slope_in = 0.1f;  // LRELU_SLOPE, both activations of the pair (model.py:46,48)
+    a.acc_mode = acc_mode;
+    a.div = div;
+    a.zrev = next_zrev(h);
+    hipError_t e = launch_pair_f32(a, h->blob + c2.off_wp, reinterpret_cast<const float*>(h->blob + c2.off_b), s);
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused fp32 pair launch for %s failed: %s", c1.key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 // ---- bf16 path -------------------------------------------------------------------------------------
 // ragged batches (vtts_hifigan_forward_ragged): every layer learns each utterance's valid rows = frames * (rows per frame)
 void set_ragged(const vtts_hifigan* h, BConvArgs& a, int L) {
@@ -926,6 +966,13 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                     }
                     return rcc;
                 }
+                if (pair_f32_wanted(h, h->layers[base], h->layers[base + 1], (int)L) && pair_f32_wanted(h, h->layers[base + 2], h->layers[base + 3], (int)L) &&
+                    pair_f32_wanted(h, h->layers[base + 4], h->layers[base + 5], (int)L)) {
+                    // fused pairs cannot run in place (a neighbour tile's halo would see updated columns): X -> T -> C -> out
+                    if ((rcc = run_pair_f32(h, h->layers[base + 0], h->layers[base + 1], cur, nb, (int)L, tT, ACC_STORE, 1.f, cs))) return rcc;
+                    if ((rcc = run_pair_f32(h, h->layers[base + 2], h->layers[base + 3], tT, nb, (int)L, tC, ACC_STORE, 1.f, cs))) return rcc;
+                    return run_pair_f32(h, h->layers[base + 4], h->layers[base + 5], tC, nb, (int)L, out, mode, div, cs);
+                }
                 for (int z = 0; z < 3 && !rcc; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
                     const Layer& c2 = h->layers[base + 2 * z + 1];
@@ -1417,7 +1464,14 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
     if (!h->blob) return fail(VTTS_ERR_STATE, "run_pair() before pack()/bind_packed()");
     if (B <= 0 || L <= 0) return fail(VTTS_ERR_INVALID, "B and L must be positive");
     Layer* l = find_layer(h, key_c1);
-    if (!l || !l->has_pair) return fail(VTTS_ERR_INVALID, "'%s' is not the first convolution of a fused ResBlock pair (bf16 handles only)", key_c1);
+    if (h->dtype == VTTS_F32) {
+        // fp32 handle: x_dev / y_dev are [B, C, L] channel-major (the fp32 engine's layout); asynchronous on `stream`
+        if (!l || l + 1 >= h->layers.data() + h->layers.size() || !l->has_wp || !(l + 1)->has_wp || (l + 1)->k != l->k || (l + 1)->dil != 1 ||
+            (l + 1)->cin != l->cin || l->cin != l->cout || !pair_f32_supported(l->cin, l->k, l->dil, L))
+            return fail(VTTS_ERR_INVALID, "'%s' is not the first convolution of a ResBlock pair the fused fp32 kernel covers (C in {32, 64, 128}, L a multiple of 4)", key_c1);
+        return run_pair_f32(h, *l, *(l + 1), x_dev, B, L, y_dev, ACC_STORE, 1.f, static_cast<hipStream_t>(stream));
+    }
+    if (!l || !l->has_pair) return fail(VTTS_ERR_INVALID, "'%s' is not the first convolution of a fused ResBlock pair", key_c1);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t n = (size_t)B * L * l->cin;
     DevBuf xbuf, ybuf;
@@ -1447,7 +1501,7 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
         if (value < 0) return fail(VTTS_ERR_INVALID, "microbatch must be >= 0");
         h->opt_microbatch = value;
     } else if (!strcmp(name, "fuse")) {
-        if (value < 0 || value > 3) return fail(VTTS_ERR_INVALID, "fuse must be 0 (per convolution), 1 (pairs), 2 (pairs + C=32 ResBlocks where faster) or 3 (... wherever supported)");
+        if (value < 0 || value > 3) return fail(VTTS_ERR_INVALID, "fuse must be 0 (per convolution), 1 (pairs), 2 (bf16: pairs + whole ResBlocks where faster; fp32: pairs at C <= 64) or 3 (... wherever supported)");
         h->opt_fuse = value;
     } else if (!strcmp(name, "streams")) {
         if (value < 0 || value > 4) return fail(VTTS_ERR_INVALID, "streams must be 1..4 (0 = the engine's default)");

@@ -72,6 +72,12 @@ void conv1d_f32_mfma_pack(const float* w_hk, int Cin, int Cout, int K, float* ou
 hipError_t launch_conv1d_f32_mfma(const ConvArgs& a, hipStream_t s);
 const char* conv1d_f32_mfma_kernel_name(int C, int K);
 
+// ---- fp32 fused ResBlock1 pair  x' = c2(lrelu(c1(lrelu(x)))) + x  (kernels_f32_pair.hip) ----
+// a = c1's ConvArgs (x, wp = c1's packed weights, bias = b1, dil, slope_in, B, L, zrev) with the OUTPUT side filled in (y, res = x,
+// acc_mode, div); wp2 / bias2 = c2's.  Bit-identical to launching the two convolutions one after the other.
+bool pair_f32_supported(int C, int K, int dil, int L);
+hipError_t launch_pair_f32(const ConvArgs& a, const void* wp2, const float* bias2, hipStream_t s);
+
 // ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
 bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
 size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K);

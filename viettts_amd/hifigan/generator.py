@@ -252,9 +252,14 @@ class Generator:
         return y
 
     def run_pair(self, key_c1: str, x: torch.Tensor) -> torch.Tensor:
-        """bf16 handles: one fused ResBlock pair, ``x`` fp32 ``[B, L, C]`` channels-last -> same shape."""
+        """One fused ResBlock pair ``x' = convs2_z(lrelu(convs1_z(lrelu(x)))) + x`` named by its first convolution.
+        bf16 handles: ``x`` fp32 ``[B, L, C]`` channels-last (rounded to bf16 on the way in) -> same shape;
+        fp32 handles: ``x`` ``[B, C, L]`` channel-major -> same shape."""
         x = x.contiguous()
-        B, L, _ = x.shape
+        if self.dtype_name == "bf16":
+            B, L, _ = x.shape
+        else:
+            B, _, L = x.shape
         y = torch.empty_like(x)
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
