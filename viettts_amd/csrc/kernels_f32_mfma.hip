@@ -63,7 +63,7 @@ struct ConvTile {
 //   element = W_hk[j][ci = chunk*CK + 2*(4*cq + e) + (lane >> 5)][co = mblk*32 + (lane & 31)]
 // i.e. for k-step (j, cp = 4*cq + e) lane l holds A[i = l&31][k = l>>5] of the 32x32x2 MFMA.
 template <class T>
-__global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
+__global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // register budget of three workgroups per CU (what the 47 KB tiles of C >= 128 allow)
     constexpr int COUT = T::COUT, MT = T::MT, NT = T::NT, WN = T::WN, CK = T::CK;
     constexpr int MR = T::MR, NR = T::NR, PA = T::PA, W = T::W, RS = T::RS, NCH = T::NCH, CQ = T::CQ, NIT = T::NIT;
 
@@ -183,17 +183,52 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvArgs a) {
     }
 
     // ---- epilogue: C/D layout col = lane&31 (time), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (channel) ----
+    // The operations of device_common.h: epilogue_store in the same order (v = acc + bias; v = v + res; ACC_ADD: v = y + v; ACC_MEAN:
+    // v = (y + v) / div), but with every residual / accumulator value of a 32 x 32 block REQUESTED before the block's first store (round 4):
+    // a.res and a.y may alias as far as the compiler knows, so the per-element form was 16 dependent load -> add -> store round trips per block.
+    const int mode = a.acc_mode;
+    const float dv = a.div;
+    const bool has_res = a.res != nullptr;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int t = t0 + wn * (NT / WN) + nr * 32 + l31;
-            if (t < L) {
+            const bool ok = t < L;
+            const int tc = ok ? t : 0;  // a masked lane reads an in-bounds address of its own row and stores nothing
+            if (!has_res && mode == ACC_STORE) {
+                if (ok) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        a.y[((long)b * COUT + co) * L + t] = acc[mr][nr][r] + a.bias[co];
+                    }
+                }
+                continue;
+            }
+            // 8 values per round trip, 32-bit element offsets inside the utterance (COUT * L < 2^31): the register budget of three workgroups per CU
+            const float* __restrict__ resb = has_res ? a.res + (long)b * COUT * L : a.y + (long)b * COUT * L;
+            float* yb = a.y + (long)b * COUT * L;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float rv[8], yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    const int off = (m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc;
+                    rv[q] = has_res ? resb[off] : 0.0f;
+                    yv[q] = mode != ACC_STORE ? yb[off] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const long idx = ((long)b * COUT + co) * L + t;
-                    epilogue_store(a, idx, acc[mr][nr][r] + a.bias[co]);
+                    const int off = co * L + tc;
+                    float v = acc[mr][nr][r] + a.bias[co];
+                    if (has_res) v = v + rv[q];
+                    if (mode == ACC_ADD) v = yv[q] + v;
+                    else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;
+                    if (ok) yb[off] = v;
                 }
             }
         }

@@ -39,9 +39,10 @@ struct PairArgsF32 {
     const float* bias2;
 };
 
-template <int C_, int KS_, int N1_, int WM_, int WN_, int CK_>
+template <int C_, int KS_, int N1_, int WM_, int WN_, int CK_, int WPS_>
 struct F32PairTile {
     static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, CK = CK_;
+    static constexpr int WPS = WPS_;                   // waves per SIMD the register budget is set for (= workgroups per CU the LDS tile allows)
     static constexpr int H2 = (KS - 1) / 2;
     static constexpr int NT2 = N1 - 2 * H2;            // outputs per workgroup
     static constexpr int MR = C / WM / 32, NR = N1 / WN / 32;
@@ -60,7 +61,7 @@ struct F32PairTile {
 };
 
 template <class T>
-__global__ __launch_bounds__(256) void resblock_pair_f32_k(PairArgsF32 p) {
+__global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p) {
     constexpr int C = T::C, KS = T::KS, N1 = T::N1, WN = T::WN, CK = T::CK, H2 = T::H2, NT2 = T::NT2;
     constexpr int MR = T::MR, NR = T::NR, NCH = T::NCH, CQ = T::CQ, NIT = T::NIT, RST = T::RST, ITER = T::ITER;
     const ConvArgs& a = p.a;
@@ -117,41 +118,61 @@ __global__ __launch_bounds__(256) void resblock_pair_f32_k(PairArgsF32 p) {
     };
     zero_acc();
 
-    float4 a_cur[MR], a_nxt[MR];
+    // A fragments: a ring of PF iterations (4 k-steps each) in flight per m-block, so a fragment is requested PF * 4 * MR * NR MFMAs (>= 2048
+    // matrix-pipe cycles) before its use — the fused kernel runs 2-4 workgroups per CU, too few waves to hide an L2 round trip behind other
+    // waves' MFMAs the way the 5-6 workgroups of the single-convolution kernel do.  The ring runs across the channel chunks and from c1
+    // straight into c2 (whose first fragments are in flight under epilogue 1).
+    constexpr int PF = 4;
+    static_assert(NIT % PF == 0, "ring slots are compile-time positions in the block loop");
+    constexpr long TOTAL = (long)NCH * NIT;
+    float4 a_ring[PF][MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) a_cur[mr] = wbase1[mr][0];
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a_ring[u][mr] = wbase1[mr][u * 64];
 
     // one convolution pass over the LDS tile (PHASE 1: c1 over the X tile, PHASE 2: c2 over the xt tile): `rs` = the tile's row stride,
     // `col0` = the column tap 0 of this lane's output column 0 reads, `dl` = the rate, `chunk` = which CK input channels of the packed A
-    // stream, `rowoff` = first tile row of that chunk
+    // stream, `rowoff` = first tile row of that chunk.  B fragments (one ds_read_b32 per lane and 32-column block) are read one k-step ahead.
     auto conv_chunk = [&](auto phase_tag, int chunk, int rowoff, int rs, int col0, int dl) {
         constexpr int PHASE = decltype(phase_tag)::value;
-        for (int it = 0; it < NIT; ++it) {
+        auto bload = [&](int it, int e, float (&dst)[NR]) {
             const int j = it / CQ;
             const int cq = it - j * CQ;
-            const long nxt = (long)chunk * NIT + it + 1;
-            const bool has_next = nxt < (long)NCH * NIT;
+            const float* xr = &xs[(rowoff + cq * 8 + 2 * e + lh) * rs + col0 + j * dl];
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                // c1's last iteration prefetches c2's first fragment (in flight under epilogue 1)
-                if constexpr (PHASE == 1) a_nxt[mr] = has_next ? wbase1[mr][nxt * 64] : wbase2[mr][0];
-                else a_nxt[mr] = has_next ? wbase2[mr][nxt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const float* xrow = &xs[(rowoff + cq * 8 + lh) * rs + col0 + j * dl];
+            for (int nr = 0; nr < NR; ++nr) dst[nr] = xr[nr * 32];
+        };
+        float bf[2][NR];
+        bload(0, 0, bf[0]);
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += PF) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bf[NR];
+            for (int u = 0; u < PF; ++u) {
+                const int it = it0 + u;
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) bf[nr] = xrow[e * 2 * rs + nr * 32];
+                for (int e = 0; e < 4; ++e) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int par = (u * 4 + e) & 1;
+                    // the next k-step's B fragment (the pass's last step reads nothing)
+                    if (e < 3) bload(it, e + 1, bf[par ^ 1]);
+                    else if (it + 1 < NIT) bload(it + 1, 0, bf[par ^ 1]);
+#pragma unroll
+                    for (int mr = 0; mr < MR; ++mr) {
+                        const float av = e == 0 ? a_ring[u][mr].x : e == 1 ? a_ring[u][mr].y : e == 2 ? a_ring[u][mr].z : a_ring[u][mr].w;
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[par][nr], acc[mr][nr], 0, 0, 0);
+                    }
+                }
+                // refill this slot with the fragment PF iterations ahead: the same pass, or (from c1's tail) c2's first ones
+                const long q = (long)chunk * NIT + it + PF;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
-                    const float av = e == 0 ? a_cur[mr].x : e == 1 ? a_cur[mr].y : e == 2 ? a_cur[mr].z : a_cur[mr].w;
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[nr], acc[mr][nr], 0, 0, 0);
+                    if constexpr (PHASE == 1) a_ring[u][mr] = q < TOTAL ? wbase1[mr][q * 64] : wbase2[mr][(q - TOTAL) * 64];
+                    else a_ring[u][mr] = wbase2[mr][(q < TOTAL ? q : TOTAL - 1) * 64];  // the tail re-reads the last fragment (in bounds, never used)
                 }
             }
-#pragma unroll
-            for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
         }
     };
 
@@ -223,35 +244,60 @@ __global__ __launch_bounds__(256) void resblock_pair_f32_k(PairArgsF32 p) {
 #pragma unroll 1
     for (int chunk = 0; chunk < NCH; ++chunk) conv_chunk(std::integral_constant<int, 2>{}, chunk, chunk * CK, RST, colbase2, 1);
 
-    // ---------------- epilogue 2: + b2, + x (residual), MRF accumulate / mean (device_common.h: epilogue_store) ----------------
+    // ---------------- epilogue 2: + b2, + x (residual), MRF accumulate / mean ----------------
+    // The same operations in the same order as device_common.h: epilogue_store — v = acc + b2; v = v + x; ACC_ADD: v = y + v; ACC_MEAN:
+    // v = (y + v) / div — but every residual (and accumulator) value of a block is REQUESTED before the first store: a.res and a.y may alias
+    // as far as the compiler knows, so the generic per-element form is a chain of 16 dependent load -> add -> store round trips per block.
+    const int mode = a.acc_mode;
+    const float dv = a.div;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int n = wn * (N1 / WN) + nr * 32 + l31;
             const int t = t0 + n;
-            if (n < NT2 && t < L) {
+            const bool ok = n < NT2 && t < L;
+            const int tc = ok ? t : 0;  // a masked lane reads an in-bounds address of its own row and stores nothing
+            constexpr int EB = T::WPS >= 4 ? 8 : 16;  // values requested per round trip (the 128-register budget of 4 waves per SIMD holds 8)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+            for (int r0 = 0; r0 < 16; r0 += EB) {
+                float rv[EB], yv[EB];
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const long idx = ((long)b * C + co) * L + t;
-                    epilogue_store(a, idx, acc[mr][nr][r] + p.bias2[co]);
+                    const long idx = ((long)b * C + co) * L + tc;
+                    rv[q] = a.res[idx];
+                    yv[q] = mode != ACC_STORE ? a.y[idx] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const int r = r0 + q;
+                    const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const long idx = ((long)b * C + co) * L + tc;
+                    float v = acc[mr][nr][r] + p.bias2[co];
+                    v = v + rv[q];
+                    if (mode == ACC_ADD) v = yv[q] + v;
+                    else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;
+                    if (ok) a.y[idx] = v;
                 }
             }
         }
 }
 
 // ---- tile table ------------------------------------------------------------------------------------
-//                                                 C   KS   N1  WM WN CK
-#ifndef VTTS_FP32_N1  // tile-geometry experiments (A/B builds)
+//                                                 C   KS   N1  WM WN CK WPS
+#ifndef VTTS_FP32_N1  // tile-geometry experiments (A/B builds): columns per workgroup and the waves per SIMD the registers are budgeted for
 #define VTTS_FP32_N1 256
+#define VTTS_FP32_WPS 4
 #endif
 #ifndef VTTS_FP64_N1
 #define VTTS_FP64_N1 128
+#define VTTS_FP64_WPS 3
 #endif
-template <int KS> using FP32 = F32PairTile<32, KS, VTTS_FP32_N1, 1, 4, 32>;
-template <int KS> using FP64 = F32PairTile<64, KS, VTTS_FP64_N1, 2, 2, 64>;
-template <int KS> using FP128 = F32PairTile<128, KS, 128, 2, 2, 64>;
+template <int KS> using FP32 = F32PairTile<32, KS, VTTS_FP32_N1, 1, 4, 32, VTTS_FP32_WPS>;
+template <int KS> using FP64 = F32PairTile<64, KS, VTTS_FP64_N1, 2, 2, 64, VTTS_FP64_WPS>;
+template <int KS> using FP128 = F32PairTile<128, KS, 128, 2, 2, 64, 2>;
 
 template <class T>
 static hipError_t launch_fp(const PairArgsF32& p, hipStream_t s) {

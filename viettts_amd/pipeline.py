@@ -12,6 +12,7 @@ overlapped: the acoustic model hands its mel over in groups as the decoder finis
 """
 from __future__ import annotations
 
+import os
 from typing import List, Dict, Optional, Sequence
 
 import numpy as np
@@ -168,10 +169,13 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
                 done = torch.cuda.Event()
                 done.record(cur)
                 host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
-                s_copy.wait_event(done)
-                with torch.cuda.stream(s_copy):
+                if os.environ.get("VTTS_PIPE_COPY_ON_CUR"):  # diagnostic switch: the read-back on the generator's own stream
                     host.copy_(w, non_blocking=True)
-                w.record_stream(s_copy)
+                else:
+                    s_copy.wait_event(done)
+                    with torch.cuda.stream(s_copy):
+                        host.copy_(w, non_blocking=True)
+                    w.record_stream(s_copy)
                 pending.append((rows, fr, host))
         if ngroups > 1:
             cur.wait_stream(s_ac)
