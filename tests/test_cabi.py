@@ -144,3 +144,24 @@ def test_integration_md_stub_matches_the_abi(lib):
     assert re.findall(r"int32_t\s+([a-z_]+)", body) == [f[0] for f in doc._fields_]
     for sym in set(re.findall(r"_lib\.(vtts_[a-z_0-9]+)", src)):
         assert hasattr(lib, sym), sym
+
+
+def test_built_library_has_no_packed_f32_valu():
+    """No kernel of the library may contain v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: on MI355X their results are wrong while another wave
+    of the SIMD streams bf16 MFMAs (round 4: the NAT decoder beside the bf16 generator; tools/kbench/pkfma_hazard.hip,
+    profiles/r04_a_pkfma_findings.md), and they cannot co-issue with MFMAs anyway (profiles/r03_a_coissue_findings.md).  Every device file
+    is built with -fno-slp-vectorize (viettts_amd/csrc/build.py); this disassembles what was actually built."""
+    import sys
+    from pathlib import Path
+
+    repo = Path(__file__).resolve().parents[1]
+    sys.path.insert(0, str(repo / "tools"))
+    from check_no_packed_f32 import count_packed_f32
+
+    from viettts_amd import _lib
+    from viettts_amd.csrc import build
+
+    assert all("-fno-slp-vectorize" in build.FILE_FLAGS.get(src, []) for src in build.SOURCES)
+    counts = count_packed_f32(Path(_lib.default_lib_path()))
+    assert len(counts) == len(build.SOURCES) and sum(m for _, m in counts.values()) > 5000  # every translation unit's code object was found and disassembled
+    assert all(pk == 0 for pk, _ in counts.values()), counts

@@ -22,9 +22,15 @@ OBJDIR = CSRC / "build"
 SOURCES = ["engine.hip", "kernels_generic.hip", "kernels_f32_mfma.hip", "kernels_f32_pair.hip", "kernels_bf16.hip", "kernels_bf16_rbg.hip", "kernels_bf16_rbk.hip", "kernels_bf16_up.hip", "nat.hip"]
 HEADERS = ["vtts_internal.h", "device_common.h", "bf16_common.h", str(ROOT / "include" / "vtts_hifigan.h"), str(ROOT / "include" / "vtts_nat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
-# The bf16 kernels must not contain packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 cannot issue while the
-# SIMD's other wave streams MFMAs: bf16_common.h, profiles/r03_a_coissue_findings.md); hipcc's SLP vectoriser is what forms them.
-FILE_FLAGS = {name: ["-fno-slp-vectorize"] for name in ("kernels_bf16.hip", "kernels_bf16_rbg.hip", "kernels_bf16_rbk.hip", "kernels_bf16_up.hip")}
+# No kernel of this library may contain packed-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); hipcc's SLP vectoriser is
+# what forms them, so every device file is built with -fno-slp-vectorize.  Two reasons, both measured on MI355X:
+#  * performance (round 3): they cannot issue while the SIMD's other wave streams MFMAs (bf16_common.h, profiles/r03_a_coissue_findings.md);
+#  * CORRECTNESS (round 4): a wave's v_pk_fma_f32 results come out WRONG (the low halves of the packed pairs) while another wave of the same
+#    SIMD streams v_mfma_f32_32x32x16_bf16 — the NAT decoder beside the bf16 generator, i.e. the overlapped text -> waveform pipeline,
+#    computed wrong mel frames for its even sentences (tools/experiments/r04/diag_pipe3.py; isolated in tools/kbench/pkfma_hazard.hip;
+#    profiles/r04_a_pkfma_findings.md).  Kernels that never run beside the bf16 engine would be safe with them, but a caller may put any
+#    two handles on two streams, so none keeps them (the fp32 convolutions lose ~1 %).
+FILE_FLAGS = {name: ["-fno-slp-vectorize"] for name in SOURCES}
 LIBNAME = "libvtts_hifigan.so"
 
 

@@ -431,10 +431,11 @@ bool pair_f32_wanted(const vtts_hifigan* h, const Layer& c1, const Layer& c2, in
     if (h->opt_kernels != 0 || h->opt_fuse < 1 || !c1.has_wp || !c2.has_wp) return false;
     if (c1.cin != c1.cout || c2.cin != c1.cin || c2.cout != c1.cin || c2.k != c1.k || c2.dil != 1) return false;
     if (!pair_f32_supported(c1.cin, c1.k, c1.dil, L)) return false;
-    // fuse = 1, 2: the narrow stages (C <= 64), where the separate convolutions are bound by their memory phases (profiles/r03_g_f32_pmc.md:
-    // MfmaUtil 0.36-0.71 at 1.3-3 TB/s); fuse = 3: C = 128 too (there the halo columns a fused pair recomputes cost about what the saved
-    // traffic gains)
-    return c1.cin <= 64 || h->opt_fuse >= 3;
+    // Where the fused pair measured faster than the two launches it replaces (64 x 1024 frames, rocprofv3 per launch, gpurun_out/r04_run3):
+    // C = 32: k = 3 / 7 / 11  -16 / -17 / -20 %;  C = 64: -13 / -6 / +-0 %;  C = 128: k = 3 -10 %, k = 7 -1 %, k = 11 +4.5 % (a fused pair
+    // recomputes KS - 1 of every 128 columns and holds 78 KB of LDS: at C = 128, k = 11 that costs more than the saved traffic gains).
+    // fuse = 1: C <= 64 only; fuse = 2 (default): + C = 128, k = 3; fuse = 3: every pair the kernel covers.
+    return c1.cin <= 64 || (h->opt_fuse >= 2 && c1.cin == 128 && c1.k == 3) || h->opt_fuse >= 3;
 }
 
 int run_pair_f32(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float* x, int B, int L, float* y, int acc_mode, float div, hipStream_t s) {

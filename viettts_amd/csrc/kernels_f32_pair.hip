@@ -291,9 +291,9 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
 #define VTTS_FP32_N1 256
 #define VTTS_FP32_WPS 4
 #endif
-#ifndef VTTS_FP64_N1
-#define VTTS_FP64_N1 128
-#define VTTS_FP64_WPS 3
+#ifndef VTTS_FP64_N1  // 256 columns (80 KB of LDS, two workgroups per CU): 64 x 1024 frames 348.3 -> 346.7 ms against 128 columns x 3 workgroups;
+#define VTTS_FP64_N1 256  // 64 columns x 5 workgroups 359.3 ms; C = 32: 512 columns 350.4, 128 columns 356.7 (gpurun_out/r04_run3/f32_ab.log)
+#define VTTS_FP64_WPS 2
 #endif
 template <int KS> using FP32 = F32PairTile<32, KS, VTTS_FP32_N1, 1, 4, 32, VTTS_FP32_WPS>;
 template <int KS> using FP64 = F32PairTile<64, KS, VTTS_FP64_N1, 2, 2, 64, VTTS_FP64_WPS>;
