@@ -26,8 +26,8 @@
 //   * epilogue fuses bias, the ResBlock residual and the MRF accumulate/mean (device_common.h).
 #include "device_common.h"
 
-#ifndef VTTS_PIN_PREFETCH
-#define VTTS_PIN_PREFETCH 0
+#ifndef VTTS_F32_PF  // A-fragment ring depth of conv1d_f32_mfma_k in iterations of 4 k-steps (A/B switch; 1 = round 3's one-ahead prefetch)
+#define VTTS_F32_PF 4
 #endif
 
 namespace vtts {
@@ -109,10 +109,16 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
 
-    // A operands for the first iteration
-    float4 a_cur[MR], a_nxt[MR];
+    // A fragments: a ring of PF iterations (4 k-steps each) in flight per m-block, running across the channel chunks (round 4: one iteration
+    // ahead left an L2 round trip exposed whenever fewer than ~4 waves per SIMD were there to cover it); B fragments are read one k-step ahead.
+    constexpr int PF = NIT % VTTS_F32_PF == 0 ? VTTS_F32_PF : (NIT % 2 == 0 ? 2 : 1);  // conv_pre: 70 iterations per chunk
+    static_assert(NIT % PF == 0, "ring slots are compile-time positions in the block loop");
+    constexpr long TOTAL = (long)NCH * NIT;
+    float4 a_ring[PF][MR];
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr) a_cur[mr] = wbase[mr][0];
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) a_ring[u][mr] = wbase[mr][(u < TOTAL ? u : TOTAL - 1) * 64];
 
     const int dil = a.dil;
     const int colbase = wn * (NT / WN) + l31 - a.pad + PA;  // + j*dil + nr*32
@@ -151,34 +157,36 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
         __syncthreads();
 
         // ---- MFMA over (tap j, channel pairs) of this chunk ----
-        for (int it = 0; it < NIT; ++it) {
+        auto bload = [&](int it, int e, float (&dst)[NR]) {
             const int j = it / CQ;
             const int cq = it - j * CQ;
-            // prefetch the next iteration's A operands (next chunk's first one included)
-            const long nxt = (long)chunk * NIT + it + 1;
-            const bool has_next = nxt < (long)NCH * NIT;
+            const float* xr = &xs[(cq * 8 + 2 * e + lh) * RS + colbase + j * dil];
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) a_nxt[mr] = has_next ? wbase[mr][nxt * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-#if VTTS_PIN_PREFETCH
-            __builtin_amdgcn_sched_barrier(0);  // keep the loads at the top: a full iteration (16 MFMAs) of cover
-#endif
-
-            const float* xrow = &xs[(cq * 8 + lh) * RS + colbase + j * dil];
+            for (int nr = 0; nr < NR; ++nr) dst[nr] = xr[nr * 32];
+        };
+        float bf[2][NR];
+        bload(0, 0, bf[0]);
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += PF) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bf[NR];
+            for (int u = 0; u < PF; ++u) {
+                const int it = it0 + u;
 #pragma unroll
-                for (int nr = 0; nr < NR; ++nr) bf[nr] = xrow[e * 2 * RS + nr * 32];
+                for (int e = 0; e < 4; ++e) {
+                    const int par = (u * 4 + e) & 1;
+                    if (e < 3) bload(it, e + 1, bf[par ^ 1]);
+                    else if (it + 1 < NIT) bload(it + 1, 0, bf[par ^ 1]);
 #pragma unroll
-                for (int mr = 0; mr < MR; ++mr) {
-                    const float av = e == 0 ? a_cur[mr].x : e == 1 ? a_cur[mr].y : e == 2 ? a_cur[mr].z : a_cur[mr].w;
+                    for (int mr = 0; mr < MR; ++mr) {
+                        const float av = e == 0 ? a_ring[u][mr].x : e == 1 ? a_ring[u][mr].y : e == 2 ? a_ring[u][mr].z : a_ring[u][mr].w;
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[nr], acc[mr][nr], 0, 0, 0);
+                        for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[par][nr], acc[mr][nr], 0, 0, 0);
+                    }
                 }
-            }
+                const long q = (long)chunk * NIT + it + PF;  // refill this slot PF iterations ahead (the tail re-reads the last fragment: in bounds, never used)
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) a_cur[mr] = a_nxt[mr];
+                for (int mr = 0; mr < MR; ++mr) a_ring[u][mr] = wbase[mr][(q < TOTAL ? q : TOTAL - 1) * 64];
+            }
         }
     }
 

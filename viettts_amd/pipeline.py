@@ -82,7 +82,7 @@ def _side_streams(device: torch.device):
 
 
 OVERLAP_MIN_FRAMES = 16384  # below this a rank's shard is one small generator pass: nothing worth overlapping
-OVERLAP_GROUPS = 4
+OVERLAP_GROUPS = 6  # 256 transcript sentences on one MI355X: 1 group 65.8 ms, 4 groups 65.1-65.4, 6 groups 63.8-63.9, 8 groups 64.6 (gpurun_out/r04_run1, r04_run6)
 
 
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
