@@ -1,0 +1,133 @@
+"""The split-operand engine (VTTS_BF16X3, "bf16x3"): the fp32 engine's layouts, schedule and entry points with the ResBlock convolutions on the bf16
+matrix pipe, every product formed from three bf16 x bf16 terms of two-term operand splits (viettts_amd/csrc/kernels_x3.hip).  It answers to
+BASELINE.json's fp32 bar (1e-4 max-abs against the reference generator); the asserts here are tighter (5e-5) and print what is observed.
+CPU emulation of the same arithmetic: tools/experiments/r04/split_precision_emulation.py (1.6-1.9e-5)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hifigan_oracle as orc
+from viettts_amd.hifigan.config import V1
+from viettts_amd.hifigan.synth import synthetic_mel, synthetic_params
+from viettts_amd.hifigan.weights import conv_specs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4    # north_star bar
+BOUND = 5e-5  # what the split arithmetic is expected to meet with margin
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def v1_params():
+    return synthetic_params(V1, 4321, "scaled")
+
+
+@pytest.fixture(scope="module")
+def gen(dev, v1_params):
+    from viettts_amd.hifigan.generator import Generator
+
+    g = Generator(V1, device=dev, dtype="bf16x3")
+    g.load_params(v1_params)
+    yield g
+    g.close()
+
+
+def _nwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 1)))
+
+
+def _pair_cases():
+    seen, out = set(), []
+    specs = conv_specs(V1)
+    for i, s in enumerate(specs):
+        if s.kind == "conv" and s.cin == s.cout and "convs1_" in s.key:
+            sig = (s.cin, s.k, s.dilation)
+            if sig not in seen:
+                seen.add(sig)
+                out.append((s, specs[i + 1]))
+    return out
+
+
+@pytest.mark.parametrize("pair", _pair_cases(), ids=lambda p: f"C{p[0].cin}k{p[0].k}d{p[0].dilation}")
+def test_x3_pair_kat(gen, v1_params, dev, pair, capsys):
+    """Every (C, k, rate) pair of V1 against the oracle's ``c2(lrelu(c1(lrelu(x)))) + x`` (vietTTS/hifigan/model.py:45-50) in fp64: lengths that are
+    no multiple of any tile, several tiles per utterance.  Error relative to the output's magnitude: ~2^-17 per operand."""
+    c1, c2 = pair
+    rng = np.random.default_rng(c1.cin * 1000 + c1.k * 10 + c1.dilation)
+    B, L = 2, {256: 301, 128: 611, 64: 1203, 32: 1203}[c1.cin]
+    x = rng.standard_normal((B, c1.cin, L)).astype(np.float32) * 2.0
+    xn = _nwc(x).astype(np.float64)
+    w1, b1 = v1_params[c1.key]["w"].astype(np.float64), v1_params[c1.key]["b"].astype(np.float64)
+    w2, b2 = v1_params[c2.key]["w"].astype(np.float64), v1_params[c2.key]["b"].astype(np.float64)
+    xt = orc.conv1d(orc.leaky_relu(xn, 0.1), w1, b1, c1.dilation, orc.get_padding(c1.k, c1.dilation))
+    ref = orc.conv1d(orc.leaky_relu(xt, 0.1), w2, b2, 1, orc.get_padding(c2.k, 1)) + xn
+    y = gen.run_pair(c1.key, torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    err = float(np.abs(_nwc(y.cpu().numpy()) - ref).max())
+    rel = err / float(np.abs(ref).max())
+    with capsys.disabled():
+        print(f"\n[bf16x3 pair C={c1.cin} k={c1.k} d={c1.dilation}] max|err| {err:.3e} ({rel:.2e} of max|ref| {np.abs(ref).max():.2f})")
+    assert rel < 3e-5, (err, rel)
+
+
+@pytest.mark.parametrize("case", ["v1_scaled_T8", "v1_scaled_T37", "v1_scaled_T512"])
+def test_x3_generator_vs_reference_golden(golden_dir, gen, dev, case, capsys):
+    """Whole generator against the reference generator's own fp64 output (tests/golden, minted by oracle/make_golden.py from
+    vietTTS/hifigan/torch_model.py through the reference's converter): the 1e-4 of BASELINE.json, asserted at 5e-5."""
+    rec = json.load(open(golden_dir / "golden_meta.json"))["cases"][case]
+    g = np.load(golden_dir / f"{case}.npz")
+    mel = torch.from_numpy(synthetic_mel(rec["B"], rec["T"], rec["mseed"])).to(dev)
+    wav, pre = gen.forward_tap(mel, "pre_tanh")
+    torch.cuda.synchronize()
+    wav, pre = wav.cpu().numpy().astype(np.float64), pre.cpu().numpy().astype(np.float64)
+    if "idx" in g.files:
+        wav, pre = wav[:, g["idx"]], pre[:, g["idx"]]
+    e_y, e_p = float(np.abs(wav - g["y64"]).max()), float(np.abs(pre - g["pre64"]).max())
+    with capsys.disabled():
+        print(f"\n[bf16x3 {case} vs the reference generator, fp64] max|dy| {e_y:.3e}  max|d pre-tanh| {e_p:.3e}")
+    assert e_y < BOUND and e_y < TOL and e_p < BOUND, (e_y, e_p)
+
+
+def test_x3_headline_shape_and_row_independence(golden_dir, gen, dev, capsys):
+    """64 x 1024 frames (the throughput shape, default two-stream schedule): rows 0, 37, 63 against the reference's fp64 output; a row of the batch
+    is bit-identical to the utterance alone; finite, inside tanh's range."""
+    rec = json.load(open(golden_dir / "golden_meta.json"))["cases"]["v1_scaled_B64_T1024"]
+    g = np.load(golden_dir / "v1_scaled_B64_T1024.npz")
+    rows, idx = rec["rows"], g["idx"]
+    mel = torch.from_numpy(synthetic_mel(64, 1024, rec["mseed"])).to(dev)
+    wav = gen(mel)
+    torch.cuda.synchronize()
+    y = wav[rows].cpu().numpy()[:, idx].astype(np.float64)
+    e_y = float(np.abs(y - g["y64"]).max())
+    with capsys.disabled():
+        print(f"\n[bf16x3 B=64 T=1024 rows {rows} vs the reference generator, fp64] max|dy| {e_y:.3e}")
+    assert e_y < BOUND and e_y < TOL
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) < 1.0
+    for b in (0, 37, 63):
+        assert torch.equal(gen(mel[b : b + 1].contiguous())[0], wav[b]), b
+
+
+def test_x3_edge_lengths_and_microbatches(gen, v1_params, dev):
+    for T in (1, 2, 3, 5):
+        mel = synthetic_mel(1, T, 100 + T)
+        want = orc.generator_forward(v1_params, mel, V1, np.float64)[..., 0]
+        got = gen(torch.from_numpy(mel).to(dev)).cpu().numpy()
+        assert got.shape == (1, 256 * T) and np.abs(got - want).max() < BOUND
+    mel = torch.from_numpy(synthetic_mel(5, 64, 21)).to(dev)
+    base = gen(mel).clone()
+    for mb in (1, 2, 5):
+        gen.set_option("microbatch", mb)
+        assert torch.equal(gen(mel), base), mb
+    gen.set_option("microbatch", 0)
+    # fuse = 0 turns the split kernels off: the handle then IS the fp32 engine
+    gen.set_option("fuse", 0)
+    f32 = gen(mel).clone()
+    gen.set_option("fuse", 2)
+    assert not torch.equal(f32, base) and float((f32 - base).abs().max()) < BOUND

@@ -17,6 +17,7 @@ MAX_KERNELS = 4
 
 VTTS_F32 = 0
 VTTS_BF16 = 1
+VTTS_BF16X3 = 2
 
 STATUS_NAMES = {
     0: "VTTS_OK",

@@ -80,6 +80,9 @@ struct Layer {
     // transposed convolution on the register-streamed kernel (kernels_bf16_up.hip): a second packing of the 3-tap form
     bool has_ug = false;
     size_t off_ug = 0, ug_bytes = 0;
+    // VTTS_BF16X3: this ResBlock convolution's split weights, [hi fragments][lo fragments] (kernels_x3.hip: pair_x3_pack)
+    bool has_x3 = false;
+    size_t off_x3 = 0;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -90,6 +93,7 @@ struct vtts_hifigan {
     vtts_hifigan_cfg cfg;
     int device = 0;
     int dtype = VTTS_F32;
+    bool x3 = false;                 // VTTS_BF16X3: dtype stays VTTS_F32 (the fp32 engine's layouts and schedule), the ResBlock pairs run on kernels_x3.hip
     int hop = 1;
     std::vector<Layer> layers;       // execution order
     int idx_pre = -1, idx_post = -1;
@@ -330,8 +334,23 @@ int build_layers(vtts_hifigan* h) {
             off = align_up(off + l.wp_floats * sizeof(float), 256);
         }
     }
+    if (h->x3 && h->cfg.resblock != 2) {
+        for (size_t r = 0; r < h->idx_res.size(); ++r)
+            for (int q = 0; q < 6; ++q) {
+                Layer& l = h->layers[h->idx_res[r] + q];
+                if (l.cin != l.cout || !pair_x3_supported(l.cin, l.k, l.dil, 4)) continue;
+                l.has_x3 = true;
+                l.off_x3 = off;
+                off = align_up(off + pair_x3_conv_bytes(l.cin, l.k), 256);
+            }
+    }
     h->blob_bytes = off;
     if (h->prof_C) h->prof_name = conv1d_f32_mfma_kernel_name(h->prof_C, h->prof_K);
+    if (h->prof_C && h->x3) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), "resblock_pair_x3_k<XTile<%d, %d,", h->prof_C, h->prof_K);
+        h->prof_name = buf;
+    }
     return VTTS_OK;
 }
 
@@ -464,6 +483,55 @@ int run_pair_f32(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float*
     a.zrev = next_zrev(h);
     hipError_t e = launch_pair_f32(a, h->blob + c2.off_wp, reinterpret_cast<const float*>(h->blob + c2.off_b), s);
     if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused fp32 pair launch for %s failed: %s", c1.key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
+// VTTS_BF16X3: the same pair on the bf16 matrix pipe with split operands (kernels_x3.hip); same buffers, same accumulate modes
+bool pair_x3_wanted(const vtts_hifigan* h, const Layer& c1, const Layer& c2, int L) {
+    return h->x3 && h->opt_kernels == 0 && h->opt_fuse >= 1 && c1.has_x3 && c2.has_x3 && c2.k == c1.k && c2.dil == 1 && c2.cin == c1.cin &&
+           pair_x3_supported(c1.cin, c1.k, c1.dil, L);
+}
+
+int run_pair_x3(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float* x, int B, int L, float* y, int acc_mode, float div, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_sb = (long)c1.cin * L;
+    a.x_sc = L;
+    a.x_st = 1;
+    a.bias = reinterpret_cast<const float*>(h->blob + c1.off_b);
+    a.res = x;
+    a.y = y;
+    a.B = B;
+    a.Cin = c1.cin;
+    a.Cout = c1.cout;
+    a.K = c1.k;
+    a.dil = c1.dil;
+    a.pad = c1.pad;
+    a.stride = 1;
+    a.L = L;
+    a.Lout = L;
+    a.slope_in = 0.1f;
+    a.acc_mode = acc_mode;
+    a.div = div;
+    a.zrev = next_zrev(h);
+    const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
+    if (prof) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            h->prof_events.emplace_back(e0, e1);
+        }
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+    }
+    hipError_t e = launch_pair_x3(a, h->blob + c1.off_x3, h->blob + c2.off_x3, reinterpret_cast<const float*>(h->blob + c2.off_b), s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+        h->prof_used++;
+        h->prof_flops += 2.0 * 2.0 * (double)B * L * c1.cin * c1.cout * c1.k;  // ALGORITHMIC flops of the two convolutions (the kernel issues 3x as many bf16 MFMA flops)
+    }
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "split-operand pair launch for %s failed: %s", c1.key.c_str(), hipGetErrorString(e));
     return VTTS_OK;
 }
 
@@ -967,6 +1035,13 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                     }
                     return rcc;
                 }
+                if (pair_x3_wanted(h, h->layers[base], h->layers[base + 1], (int)L) && pair_x3_wanted(h, h->layers[base + 2], h->layers[base + 3], (int)L) &&
+                    pair_x3_wanted(h, h->layers[base + 4], h->layers[base + 5], (int)L)) {
+                    // VTTS_BF16X3: X -> T -> C -> out as the fused fp32 pairs below
+                    if ((rcc = run_pair_x3(h, h->layers[base + 0], h->layers[base + 1], cur, nb, (int)L, tT, ACC_STORE, 1.f, cs))) return rcc;
+                    if ((rcc = run_pair_x3(h, h->layers[base + 2], h->layers[base + 3], tT, nb, (int)L, tC, ACC_STORE, 1.f, cs))) return rcc;
+                    return run_pair_x3(h, h->layers[base + 4], h->layers[base + 5], tC, nb, (int)L, out, mode, div, cs);
+                }
                 if (pair_f32_wanted(h, h->layers[base], h->layers[base + 1], (int)L) && pair_f32_wanted(h, h->layers[base + 2], h->layers[base + 3], (int)L) &&
                     pair_f32_wanted(h, h->layers[base + 4], h->layers[base + 5], (int)L)) {
                     // fused pairs cannot run in place (a neighbour tile's halo would see updated columns): X -> T -> C -> out
@@ -1045,7 +1120,7 @@ VTTS_API const char* vtts_last_error(void) { return g_last_error.c_str(); }
 VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dtype, vtts_hifigan** out) {
     if (!cfg || !out) return fail(VTTS_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (dtype != VTTS_F32 && dtype != VTTS_BF16) return fail(VTTS_ERR_INVALID, "unknown dtype %d", dtype);
+    if (dtype != VTTS_F32 && dtype != VTTS_BF16 && dtype != VTTS_BF16X3) return fail(VTTS_ERR_INVALID, "unknown dtype %d", dtype);
     if (cfg->num_upsamples < 1 || cfg->num_upsamples > VTTS_MAX_UPSAMPLES)
         return fail(VTTS_ERR_INVALID, "num_upsamples %d out of range", cfg->num_upsamples);
     if (cfg->num_kernels < 1 || cfg->num_kernels > VTTS_MAX_KERNELS)
@@ -1074,7 +1149,8 @@ VTTS_API int vtts_hifigan_create(const vtts_hifigan_cfg* cfg, int device, int dt
     h->cfg = *cfg;
     if (h->cfg.resblock == 0) h->cfg.resblock = 1;
     h->device = device;
-    h->dtype = dtype;
+    h->dtype = dtype == VTTS_BF16X3 ? VTTS_F32 : dtype;
+    h->x3 = dtype == VTTS_BF16X3;
     const int rc = build_layers(h);
     if (rc != VTTS_OK) {
         delete h;
@@ -1233,6 +1309,7 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
         if (h->dtype == VTTS_BF16) break;
         memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
         memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
+        if (l.has_x3) pair_x3_pack(l.w.data(), l.cin, l.k, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
         if (l.has_wp && l.kind == KIND_CONV)
             conv1d_f32_mfma_pack(l.w.data(), l.cin, l.cout, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));
         else if (l.has_wp)
@@ -1465,6 +1542,8 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
     if (!h->blob) return fail(VTTS_ERR_STATE, "run_pair() before pack()/bind_packed()");
     if (B <= 0 || L <= 0) return fail(VTTS_ERR_INVALID, "B and L must be positive");
     Layer* l = find_layer(h, key_c1);
+    if (h->x3 && l && l + 1 < h->layers.data() + h->layers.size() && pair_x3_wanted(h, *l, *(l + 1), L))
+        return run_pair_x3(h, *l, *(l + 1), x_dev, B, L, y_dev, ACC_STORE, 1.f, static_cast<hipStream_t>(stream));
     if (h->dtype == VTTS_F32) {
         // fp32 handle: x_dev / y_dev are [B, C, L] channel-major (the fp32 engine's layout); asynchronous on `stream`
         if (!l || l + 1 >= h->layers.data() + h->layers.size() || !l->has_wp || !(l + 1)->has_wp || (l + 1)->k != l->k || (l + 1)->dil != 1 ||

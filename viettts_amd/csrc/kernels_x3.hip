@@ -1,0 +1,377 @@
+// Fused ResBlock1 pair on the bf16 matrix pipe with SPLIT operands ("bf16x3"):   x' = c2(lrelu(c1(lrelu(x)))) + x
+// (vietTTS/hifigan/model.py:45-50) at fp32-grade accuracy.
+//
+// Why (round 4, profiles/r04_b_split_findings.md): gfx950's bf16 MFMA rate is 16x its fp32 MFMA rate, and BASELINE.json's 1e-4 is only met by
+// the fp32 engine.  Write every operand as the sum of two bf16 terms, v = v0 + v1 with v0 = bf16(v), v1 = bf16(v - v0) (16 significand bits),
+// and form a product from three bf16 x bf16 terms accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
+//     x w  ~=  x1 w0 + x0 w1 + x0 w0                  (the dropped x1 w1 is 2^-18 of the product, as is the two-term split's own residual)
+// Whole generator, CPU emulation against the fp64 oracle: max-abs 1.6-1.9e-5 on the waveform (bf16 operands: 1.0e-2; fp32: 9e-7) — 5x inside
+// the 1e-4 bar — for 3/16 of the fp32 MFMA time.
+//
+// This kernel is a drop-in for the fp32 engine's pair launches (kernels_f32_pair.hip): activations stay fp32, CHANNEL-MAJOR [B][C][L] in HBM (so
+// conv_pre, the transposed convolutions, conv_post and everything element-wise remain the fp32 engine's exact kernels), only the two
+// convolutions' products take the split route.  One workgroup = 8 waves = C output channels x N1 columns:
+//   * staging: lane <-> time step (a wave reads 64 consecutive floats of one channel: coalesced), 8 channels per thread and unit;
+//     LeakyReLU in fp32, split, two 16-byte ds_write_b128 into a HI and a LO tile — channels-last bf16 rows with the bf16 engine's
+//     conflict-free layouts (bf16_common.h: tile_off), i.e. the transposition costs no extra pass;
+//   * MFMA loops: wave tile 64 x 64 (32 x 64 at C = 32); per k-step 2 x 2 A fragments (weights hi / lo, host-packed in A-fragment order,
+//     straight from L2 through a register ring) and 2 x 2 B fragments (tile hi / lo, one k-step ahead) feed 12 MFMAs — 2/3 of the bf16
+//     engine's operand traffic per MFMA; small terms first;
+//   * epilogue 1: + b1, LeakyReLU, the reference's zero padding of xt, split, into the xt tiles (hi / lo) over the dead X tiles;
+//   * epilogue 2: + b2, + x (fp32, from HBM / L2), MRF accumulate / mean as device_common.h: epilogue_store, fp32 stores — in the MFMA
+//     accumulator layout a half-wave holds 32 consecutive time steps of one channel: coalesced 128-byte rows, no lane exchange.
+// LDS: two tiles of up to 78 KB -> one workgroup of 8 waves per CU (two waves per SIMD cover each other's fragment latencies).
+#include <string.h>
+
+#include <type_traits>
+
+#include "bf16_common.h"
+#include "device_common.h"
+
+namespace vtts {
+
+constexpr int X3_XCD_MIN_TILES = 64;
+
+struct PairArgsX3 {
+    ConvArgs a;          // x, bias (b1), dil, slope_in, B, L, zrev; output side: y, res (= x), acc_mode, div
+    const void* w1;      // c1: [hi fragments][lo fragments], each pair_g_pack_geom(C, K) order
+    const void* w2;      // c2 likewise
+    const float* bias2;
+};
+
+template <int C_, int KS_, int N1_, int WM_, int WN_, int XC_ = C_>
+struct XTile {
+    static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, XC = XC_, NXC = C / XC;
+    static constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
+    static constexpr int MR = C / WM / 32, NR = N1 / WN / 32;
+    static constexpr int H2 = (KS - 1) / 2, MAXDIL = 5, NT2 = N1 - 2 * H2;
+    static constexpr int SPR1 = XC / 8, P1 = XC * 2;    // X tile (one channel chunk): 16-byte slots / bytes per row
+    static constexpr int SPR2 = C / 8, P2 = C * 2;      // xt tile (all channels)
+    static constexpr int KSTEPS = C / 16, KSX = XC / 16, MB = C / 32;
+    static constexpr int PA = KSX >= 4 ? 3 : 1, RA = PA + 1;  // A-fragment ring: k-steps ahead / slots
+    static constexpr int ROWST = N1 + 2 * H2;
+    static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;  // one plane (hi or lo) of one convolution
+    static __host__ __device__ constexpr int plane_bytes(int dil) {
+        const int bx = tile_rows16(N1 + 2 * H2 * dil) * P1, bt = tile_rows16(ROWST) * P2;
+        return bx > bt ? bx : bt;
+    }
+    static __host__ __device__ constexpr int lds_bytes(int dil) { return 2 * plane_bytes(dil); }
+    static_assert(C % (WM * 32) == 0 && N1 % (WN * 32) == 0 && C % XC == 0, "tiling");
+    static_assert(KSX % RA == 0 && KSTEPS % RA == 0, "ring slots are compile-time positions in a tap's k-steps");
+    static_assert(2 * plane_bytes(MAXDIL) <= 160 * 1024, "LDS budget");
+};
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3_k(PairArgsX3 p) {
+    constexpr int C = T::C, KS = T::KS, N1 = T::N1, WN = T::WN, H2 = T::H2, NT2 = T::NT2, MR = T::MR, NR = T::NR;
+    constexpr int SPR1 = T::SPR1, SPR2 = T::SPR2, XC = T::XC, NXC = T::NXC, KSX = T::KSX, KSTEPS = T::KSTEPS, MB = T::MB;
+    constexpr int PA = T::PA, RA = T::RA, THREADS = T::THREADS, NWAVES = T::NWAVES;
+    const ConvArgs& a = p.a;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int dil = a.dil;
+    unsigned char* const thi = lds;
+    unsigned char* const tlo = lds + T::plane_bytes(dil);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lh = lane >> 5;
+    const int L = a.L;
+    int tile = blockIdx.x;
+    if (gridDim.x >= X3_XCD_MIN_TILES) {  // XCD-aware tile order (as the other pair kernels): XCD blockIdx.x % 8 takes a contiguous eighth of the tiles
+        const int nt = (L + NT2 - 1) / NT2, r = (int)((blockIdx.x + blockIdx.z) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
+        tile = lo + (int)(blockIdx.x >> 3);
+        if (tile >= hi) return;
+    }
+    const int t0 = tile * NT2;
+    if (t0 >= L) return;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int h1 = H2 * dil;
+    const int rowsx = N1 + 2 * h1;           // X rows: times t0 - H2 - h1 ...
+    const float* __restrict__ xb = a.x + (long)b * C * L;
+    const int m0 = wm * (C / T::WM);         // first output channel of this wave
+    const float slope = a.slope_in;
+
+    // two bf16 terms of two fp32 values: (hi pair, lo pair), round-to-nearest-even; v - float(hi) is exact in fp32
+    auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
+        hi = pack_bf16x2(v0, v1);
+        lo = pack_bf16x2(v0 - bf16_lo(hi), v1 - bf16_hi(hi));
+    };
+
+    // ---------------- X tile (channel chunk xc): lane <-> time step, 8 channels per unit; LeakyReLU, split, swizzled ds_write_b128 x 2 ----------------
+    auto stage_x = [&](int xc) {
+        const int tx0 = t0 - H2 - h1;
+        const int nblk = (rowsx + 63) >> 6;
+        const int units = nblk * SPR1;  // (64-row block, 16-byte slot)
+        const float* __restrict__ xc0 = xb + (long)(xc * XC) * L;
+        constexpr int UB = 2;           // units in flight per thread: 16 dword loads
+        for (int u0 = wave * UB; u0 < units; u0 += NWAVES * UB) {
+            float v[UB][8];
+            int row[UB], slot[UB];
+            bool live[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int u = u0 + q < units ? u0 + q : units - 1;
+                live[q] = u0 + q < units;
+                slot[q] = u % SPR1;
+                row[q] = (u / SPR1) * 64 + lane;
+                const int t = tx0 + row[q];
+                const bool ok = live[q] && row[q] < rowsx && t >= 0 && t < L;
+                const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+                const float* __restrict__ g = xc0 + (long)(slot[q] * 8) * L + tc;  // unconditional loads from clamped addresses, masked afterwards
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * L];
+                if (!ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q][e] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                if (!live[q] || row[q] >= rowsx) continue;
+                uint4 h4, l4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] = lrelu(v[q][e], slope);
+                split2(v[q][0], v[q][1], h4.x, l4.x);
+                split2(v[q][2], v[q][3], h4.y, l4.y);
+                split2(v[q][4], v[q][5], h4.z, l4.z);
+                split2(v[q][6], v[q][7], h4.w, l4.w);
+                const int off = tile_off<SPR1>(row[q], slot[q]);
+                *reinterpret_cast<uint4*>(thi + off) = h4;
+                *reinterpret_cast<uint4*>(tlo + off) = l4;
+            }
+        }
+    };
+
+    f32x16 acc[MR][NR];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+    };
+
+    // ---- one convolution pass over the LDS tiles: acc += W[:, chunk] (*) tile, three bf16 products per operand pair ----
+    // A fragment (plane, tap, ks, mr): 16 bytes per lane at  w + plane*CONV_BYTES + (((tap*KSTEPS + ks0 + ks)*MB + wm*MR + mr)*64 + lane)*16
+    // B fragment (plane, tap, ks, nr): tile row  n + tap*dl  (n = this lane's output column), 16-byte slot 2*ks + lh of that row
+    const int rowbase0 = wn * (N1 / WN) + l31;
+    auto conv_phase = [&](const unsigned char* __restrict__ w, int dl, auto sprb_tag, auto nks_tag, int ks0) {
+        constexpr int SPRB = decltype(sprb_tag)::value, NKS = decltype(nks_tag)::value;
+        constexpr int NSTEPS = KS * NKS;
+        const uint4* __restrict__ ahi = reinterpret_cast<const uint4*>(w) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
+        const uint4* __restrict__ alo = reinterpret_cast<const uint4*>(w + T::CONV_BYTES) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
+        bf16x8 af[RA][MR][2], bf[2][NR][2];
+        auto load_a = [&](int s, int slot) {  // flat step s = tap*NKS + ks of this pass (past the end: re-read the last step, never used)
+            const int sc = s < NSTEPS ? s : NSTEPS - 1;
+            const int tap = sc / NKS, ks = sc - tap * NKS;
+            const size_t o = (size_t)((tap * KSTEPS + ks) * MB) * 64;
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr) {
+                af[slot][mr][0] = __builtin_bit_cast(bf16x8, ahi[o + (size_t)mr * 64]);
+                af[slot][mr][1] = __builtin_bit_cast(bf16x8, alo[o + (size_t)mr * 64]);
+            }
+        };
+        auto load_b = [&](int s, int par) {
+            const int sc = s < NSTEPS ? s : NSTEPS - 1;
+            const int tap = sc / NKS, ks = sc - tap * NKS;
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int off = tile_off<SPRB>(rowbase0 + tap * dl + nr * 32, ks * 2 + lh);
+                bf[par][nr][0] = *reinterpret_cast<const bf16x8*>(thi + off);
+                bf[par][nr][1] = *reinterpret_cast<const bf16x8*>(tlo + off);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < PA; ++s) load_a(s, s % RA);
+        load_b(0, 0);
+        static_assert(NKS % RA == 0 && NKS % 2 == 0, "ring slot / B parity are compile-time positions in a tap");
+#pragma unroll 1
+        for (int s0 = 0; s0 < NSTEPS; s0 += NKS) {  // one tap per iteration
+#pragma unroll
+            for (int i = 0; i < NKS; ++i) {
+                load_a(s0 + i + PA, (i + PA) % RA);
+                load_b(s0 + i + 1, (i + 1) & 1);
+                const int sl = i % RA, par = i & 1;
+                // small terms first; MR * NR independent accumulators between two MFMAs on the same one
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][1], bf[par][nr][0], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][0], bf[par][nr][1], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][0], bf[par][nr][0], acc[mr][nr], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---------------- phase 1: xt = c1(lrelu(x)); column n <-> time t0 - H2 + n; tap j reads X row n + j*dil ----------------
+    zero_acc();
+#pragma unroll
+    for (int xc = 0; xc < NXC; ++xc) {
+        if (xc > 0) __syncthreads();  // every wave is done reading the previous channel chunk
+        stage_x(xc);
+        __syncthreads();
+        conv_phase(static_cast<const unsigned char*>(p.w1), dil, std::integral_constant<int, SPR1>{}, std::integral_constant<int, KSX>{}, xc * KSX);
+    }
+    __syncthreads();  // every wave is done reading the X tiles
+
+    auto swap_pair = [](unsigned& pd, unsigned& qd) {
+        auto r = __builtin_amdgcn_permlane32_swap(pd, qd, false, false);
+        pd = r[0];
+        qd = r[1];
+    };
+
+    // ---------------- epilogue 1: + b1, LeakyReLU, zero outside [0, L), split -> xt tiles ----------------
+    // A lane's accumulators of one 32 x 32 block: column (time) l31, rows (channels) 8*rq + 4*lh + i, r = 4*rq + i.  After the exchange across
+    // the wave halves lh = 0 owns channels 16p .. 16p+7 and lh = 1 owns 16p+8 .. 16p+15 of the 16-channel half p (as the bf16 pair kernel).
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int cb = m0 + mr * 32 + 16 * pp;
+            float bv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bv[e] = a.bias[cb + 8 * (e >> 2) + 4 * lh + (e & 3)];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int row = wn * (N1 / WN) + nr * 32 + l31;
+                const int tt = t0 - H2 + row;
+                const bool ok = tt >= 0 && tt < L;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = lrelu(acc[mr][nr][8 * pp + e] + bv[e], slope);
+                    if (!ok) v[e] = 0.0f;  // c2's own zero padding applies to xt
+                }
+                unsigned hp0, hp1, hq0, hq1, lp0, lp1, lq0, lq1;
+                split2(v[0], v[1], hp0, lp0);
+                split2(v[2], v[3], hp1, lp1);
+                split2(v[4], v[5], hq0, lq0);
+                split2(v[6], v[7], hq1, lq1);
+                swap_pair(hp0, hq0);
+                swap_pair(hp1, hq1);
+                swap_pair(lp0, lq0);
+                swap_pair(lp1, lq1);
+                const int off = tile_off<SPR2>(row, (cb >> 3) + lh);
+                *reinterpret_cast<uint4*>(thi + off) = make_uint4(hp0, hp1, hq0, hq1);
+                *reinterpret_cast<uint4*>(tlo + off) = make_uint4(lp0, lp1, lq0, lq1);
+            }
+        }
+    for (int u = tid; u < 2 * H2 * SPR2; u += THREADS) {  // rows N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
+        const int off = tile_off<SPR2>(N1 + u % (2 * H2), u / (2 * H2));
+        *reinterpret_cast<uint4*>(thi + off) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(tlo + off) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    zero_acc();
+    __syncthreads();  // xt tiles written
+
+    // ---------------- phase 2: c2 over the xt tiles (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
+    conv_phase(static_cast<const unsigned char*>(p.w2), 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0);
+
+    // ---------------- epilogue 2: + b2, + x, MRF accumulate / mean (the operations of device_common.h: epilogue_store, loads batched) ----------------
+    const int mode = a.acc_mode;
+    const float dv = a.div;
+    const float* __restrict__ resb = a.res + (long)b * C * L;
+    float* yb = a.y + (long)b * C * L;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int n = wn * (N1 / WN) + nr * 32 + l31;
+            const int t = t0 + n;
+            const bool ok = n < NT2 && t < L;
+            const int tc = ok ? t : 0;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float rv[8], yv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    const int off = (m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc;
+                    rv[q] = resb[off];
+                    yv[q] = mode != ACC_STORE ? yb[off] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float v = acc[mr][nr][r] + p.bias2[co];
+                    v = v + rv[q];
+                    if (mode == ACC_ADD) v = yv[q] + v;
+                    else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;
+                    if (ok) yb[co * L + tc] = v;
+                }
+            }
+        }
+}
+
+// ---- tile table ------------------------------------------------------------------------------------
+//                                        C   KS   N1  WM WN  XC
+template <int KS> using X256 = XTile<256, KS, 128, 4, 2, 128>;
+template <int KS> using X128 = XTile<128, KS, 256, 2, 4>;
+template <int KS> using X64 = XTile<64, KS, 512, 1, 8>;
+template <int KS> using X32 = XTile<32, KS, 512, 1, 8>;
+
+template <class T>
+static hipError_t launch_x3(const PairArgsX3& p, hipStream_t s) {
+    static DynLdsOnce once;
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_x3_k<T>), T::lds_bytes(T::MAXDIL), once); e != hipSuccess) return e;
+    dim3 grid((p.a.L + T::NT2 - 1) / T::NT2, 1, p.a.B);
+    if ((int)grid.x >= X3_XCD_MIN_TILES) grid.x = (grid.x + 7) / 8 * 8;
+    hipLaunchKernelGGL(resblock_pair_x3_k<T>, grid, dim3(T::THREADS), T::lds_bytes(p.a.dil), s, p);
+    return hipGetLastError();
+}
+
+template <template <int> class TT>
+static hipError_t launch_x3_ks(const PairArgsX3& p, int K, hipStream_t s) {
+    switch (K) {
+        case 3: return launch_x3<TT<3>>(p, s);
+        case 7: return launch_x3<TT<7>>(p, s);
+        case 11: return launch_x3<TT<11>>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+bool pair_x3_supported(int C, int K, int dil, int L) {
+    return (C == 256 || C == 128 || C == 64 || C == 32) && (K == 3 || K == 7 || K == 11) && dil >= 1 && dil <= 5 && L >= 1 && (long)C * L < (1l << 31);
+}
+
+// bytes of one convolution's packed weights: hi plane + lo plane, each in pair_g_pack_geom(C, K) order
+size_t pair_x3_conv_bytes(int C, int K) { return 2 * (size_t)K * C * C * 2; }
+
+// Haiku [K][Cin][Cout] fp32 -> [hi fragments][lo fragments] (bf16, A-fragment order of the bf16 pair kernel)
+void pair_x3_pack(const float* w_hk, int C, int K, unsigned short* out) {
+    const size_t n = (size_t)K * C * C;
+    float* hi = new float[2 * n];
+    float* lo = hi + n;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned u;
+        memcpy(&u, &w_hk[i], 4);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;  // round to nearest even
+        memcpy(&hi[i], &u, 4);
+        lo[i] = w_hk[i] - hi[i];  // exact; bf16_pack rounds it to bf16
+    }
+    const BPackGeom g = pair_g_pack_geom(C, K);
+    bf16_pack(hi, C, g, out);
+    bf16_pack(lo, C, g, out + n);
+    delete[] hi;
+}
+
+hipError_t launch_pair_x3(const ConvArgs& a, const void* w1, const void* w2, const float* bias2, hipStream_t s) {
+    PairArgsX3 p{a, w1, w2, bias2};
+    switch (a.Cin) {
+        case 256: return launch_x3_ks<X256>(p, a.K, s);
+        case 128: return launch_x3_ks<X128>(p, a.K, s);
+        case 64: return launch_x3_ks<X64>(p, a.K, s);
+        case 32: return launch_x3_ks<X32>(p, a.K, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vtts

@@ -78,6 +78,13 @@ const char* conv1d_f32_mfma_kernel_name(int C, int K);
 bool pair_f32_supported(int C, int K, int dil, int L);
 hipError_t launch_pair_f32(const ConvArgs& a, const void* wp2, const float* bias2, hipStream_t s);
 
+// ---- split-operand ("bf16x3") fused ResBlock1 pair on the bf16 matrix pipe, fp32 channel-major activations (kernels_x3.hip) ----
+// a as for launch_pair_f32 (a.wp unused); w1 / w2 = the two convolutions' packed weights, each [hi fragments][lo fragments] (pair_x3_pack)
+bool pair_x3_supported(int C, int K, int dil, int L);
+size_t pair_x3_conv_bytes(int C, int K);
+void pair_x3_pack(const float* w_hk, int C, int K, unsigned short* out);
+hipError_t launch_pair_x3(const ConvArgs& a, const void* w1, const void* w2, const float* bias2, hipStream_t s);
+
 // ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
 bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
 size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K);

@@ -40,7 +40,7 @@ class Generator:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise ValueError("Generator needs a ROCm device ('cuda:N'); there is no CPU path")
-        self.dtype = {"f32": _lib.VTTS_F32, "bf16": _lib.VTTS_BF16}[dtype]
+        self.dtype = {"f32": _lib.VTTS_F32, "bf16": _lib.VTTS_BF16, "bf16x3": _lib.VTTS_BF16X3}[dtype]  # bf16x3: the fp32 engine's layouts and entry points
         self.dtype_name = dtype
         self._h = C.c_void_p(0)
         cs = _lib.make_cfg(cfg)
