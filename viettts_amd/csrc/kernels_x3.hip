@@ -39,9 +39,10 @@ struct PairArgsX3 {
     const float* bias2;
 };
 
-template <int C_, int KS_, int N1_, int WM_, int WN_, int XC_ = C_>
+template <int C_, int KS_, int N1_, int WM_, int WN_, int XC_ = C_, int WPS_ = 2>
 struct XTile {
     static constexpr int C = C_, KS = KS_, N1 = N1_, WM = WM_, WN = WN_, XC = XC_, NXC = C / XC;
+    static constexpr int WPS = WPS_;                    // waves per SIMD the registers are budgeted for (workgroups per CU x waves / 4)
     static constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
     static constexpr int MR = C / WM / 32, NR = N1 / WN / 32;
     static constexpr int H2 = (KS - 1) / 2, MAXDIL = 5, NT2 = N1 - 2 * H2;
@@ -62,7 +63,7 @@ struct XTile {
 };
 
 template <class T>
-__global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3_k(PairArgsX3 p) {
+__global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArgsX3 p) {
     constexpr int C = T::C, KS = T::KS, N1 = T::N1, WN = T::WN, H2 = T::H2, NT2 = T::NT2, MR = T::MR, NR = T::NR;
     constexpr int SPR1 = T::SPR1, SPR2 = T::SPR2, XC = T::XC, NXC = T::NXC, KSX = T::KSX, KSTEPS = T::KSTEPS, MB = T::MB;
     constexpr int PA = T::PA, RA = T::RA, THREADS = T::THREADS, NWAVES = T::NWAVES;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3
         const int nblk = (rowsx + 63) >> 6;
         const int units = nblk * SPR1;  // (64-row block, 16-byte slot)
         const float* __restrict__ xc0 = xb + (long)(xc * XC) * L;
-        constexpr int UB = 2;           // units in flight per thread: 16 dword loads
+        constexpr int UB = 4;           // units in flight per thread: 32 dword loads
         for (int u0 = wave * UB; u0 < units; u0 += NWAVES * UB) {
             float v[UB][8];
             int row[UB], slot[UB];
@@ -159,17 +160,20 @@ __global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3
     auto conv_phase = [&](const unsigned char* __restrict__ w, int dl, auto sprb_tag, auto nks_tag, int ks0) {
         constexpr int SPRB = decltype(sprb_tag)::value, NKS = decltype(nks_tag)::value;
         constexpr int NSTEPS = KS * NKS;
-        const uint4* __restrict__ ahi = reinterpret_cast<const uint4*>(w) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
-        const uint4* __restrict__ alo = reinterpret_cast<const uint4*>(w + T::CONV_BYTES) + ((size_t)ks0 * MB + wm * MR) * 64 + lane;
+        // weight fragments by buffer loads (the bf16 pair kernel's lean addressing): the lane's offset in a VGPR, the k-step's in an SGPR, the
+        // m-block an immediate — no per-load 64-bit address arithmetic on the issue port the MFMAs share
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(w), 0, (int)(2 * T::CONV_BYTES), 0x00020000);
+        const unsigned a_voff = (unsigned)((wm * MR) * 64 + lane) * 16;
         bf16x8 af[RA][MR][2], bf[2][NR][2];
         auto load_a = [&](int s, int slot) {  // flat step s = tap*NKS + ks of this pass (past the end: re-read the last step, never used)
             const int sc = s < NSTEPS ? s : NSTEPS - 1;
             const int tap = sc / NKS, ks = sc - tap * NKS;
-            const size_t o = (size_t)((tap * KSTEPS + ks) * MB) * 64;
+            const int soff = ((tap * KSTEPS + ks0 + ks) * MB) * 1024;
 #pragma unroll
             for (int mr = 0; mr < MR; ++mr) {
-                af[slot][mr][0] = __builtin_bit_cast(bf16x8, ahi[o + (size_t)mr * 64]);
-                af[slot][mr][1] = __builtin_bit_cast(bf16x8, alo[o + (size_t)mr * 64]);
+                af[slot][mr][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + mr * 1024, soff, 0));
+                af[slot][mr][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + mr * 1024, soff + (int)T::CONV_BYTES, 0));
             }
         };
         auto load_b = [&](int s, int par) {
@@ -206,6 +210,20 @@ __global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][0], bf[par][nr][0], acc[mr][nr], 0, 0, 0);
+                // keep hipcc from sinking the look-ahead loads to their uses (it does, to save registers: the first build waited for every
+                // fragment right in front of the MFMA that consumes it) and spread them between this step's MFMAs (the bf16 pair kernel's
+                // pin_step): one MFMA, then the next pending A load (VMEM) or B read (DS)
+                constexpr int NMF = 3 * MR * NR, NA = 2 * MR, NB = 2 * NR;
+                int done = 0;
+#pragma unroll
+                for (int m = 0; m < NMF; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    const int upto = (m + 1) * (NA + NB) / NMF;
+                    for (; done < upto; ++done) {
+                        if (done < NA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
             }
         }
     };
@@ -274,13 +292,25 @@ __global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3
     // ---------------- phase 2: c2 over the xt tiles (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
     conv_phase(static_cast<const unsigned char*>(p.w2), 1, std::integral_constant<int, SPR2>{}, std::integral_constant<int, KSTEPS>{}, 0);
 
-    // ---------------- epilogue 2: + b2, + x, MRF accumulate / mean (the operations of device_common.h: epilogue_store, loads batched) ----------------
+    // ---------------- epilogue 2: + b2, + x, MRF accumulate / mean (the operations of device_common.h: epilogue_store, in its order) ----------------
+    // Every residual value of an m-block is requested before the first one is used (the ring and fragment registers are dead here): MR
+    // exposed round trips per tile instead of eight — it matters in a one-workgroup-per-CU kernel, nobody else's MFMAs cover it.  (Requested ahead
+    // of the c2 loop they would arrive for free, but 64 more live registers spill: 94 VGPRs, measured by the compiler.)
     const int mode = a.acc_mode;
     const float dv = a.div;
     const float* __restrict__ resb = a.res + (long)b * C * L;
     float* yb = a.y + (long)b * C * L;
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
+    for (int mr = 0; mr < MR; ++mr) {
+        float rres[NR][16];  // one m-block's residual values per round trip (all MR * NR * 16 at once spill)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int n = wn * (N1 / WN) + nr * 32 + l31;
+            const int t = t0 + n;
+            const int tc = (n < NT2 && t < L) ? t : 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rres[nr][r] = resb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc];
+        }
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
             const int n = wn * (N1 / WN) + nr * 32 + l31;
@@ -289,34 +319,58 @@ __global__ __launch_bounds__(T::THREADS, T::THREADS / 256) void resblock_pair_x3
             const int tc = ok ? t : 0;
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
-                float rv[8], yv[8];
+                float yv[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
-                    const int off = (m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc;
-                    rv[q] = resb[off];
-                    yv[q] = mode != ACC_STORE ? yb[off] : 0.0f;
+                    yv[q] = mode != ACC_STORE ? yb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc] : 0.0f;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     float v = acc[mr][nr][r] + p.bias2[co];
-                    v = v + rv[q];
+                    v = v + rres[nr][r];
                     if (mode == ACC_ADD) v = yv[q] + v;
                     else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;
                     if (ok) yb[co * L + tc] = v;
                 }
             }
         }
+    }
 }
 
 // ---- tile table ------------------------------------------------------------------------------------
-//                                        C   KS   N1  WM WN  XC
-template <int KS> using X256 = XTile<256, KS, 128, 4, 2, 128>;
-template <int KS> using X128 = XTile<128, KS, 256, 2, 4>;
-template <int KS> using X64 = XTile<64, KS, 512, 1, 8>;
-template <int KS> using X32 = XTile<32, KS, 512, 1, 8>;
+// Two geometries were measured per class (64 x 1024 frames, rocprofv3 per launch, gpurun_out/r04_run11): ONE 8-wave workgroup per CU on full-width
+// tiles (two waves per SIMD cover each other's fragment latencies; every phase is workgroup-wide) against TWO 4-wave workgroups per CU on
+// half-width tiles with the X tile staged 64 channels at a time (one's staging / epilogues under the other's MFMAs; more halo per output):
+//   C = 128: k = 11  7.45 vs 7.52 ms, k = 7  5.20 vs 5.17, k = 3  3.07 vs 2.90      C = 64: 4.46 vs 4.06, 3.32 vs 3.09, 2.36 vs 2.18
+//   C = 32 : k = 11  3.55 vs 3.20, k = 7  2.80 vs 2.74, k = 3  1.92 vs 2.29           C = 256 (two workgroups do not fit): 3.56 / 2.37 / 1.21
+// The table takes the faster one per class (VTTS_X3_GEOM: 0 = this table, 1 = one workgroup everywhere, 2 = two workgroups wherever they fit).
+//                                        C   KS   N1  WM WN  XC  WPS
+#ifndef VTTS_X3_GEOM
+#define VTTS_X3_GEOM 0
+#endif
+template <int KS> using X256 = XTile<256, KS, 128, 4, 2, 128, 2>;
+template <int KS> using X128one = XTile<128, KS, 256, 2, 4, 128, 2>;
+template <int KS> using X128two = XTile<128, KS, 128, 2, 2, 64, 2>;
+template <int KS> using X64one = XTile<64, KS, 512, 1, 8, 64, 2>;
+template <int KS> using X64two = XTile<64, KS, 256, 1, 4, 64, 2>;
+template <int KS> using X32one = XTile<32, KS, 512, 1, 8, 32, 2>;
+template <int KS> using X32two = XTile<32, KS, 512, 1, 4, 32, 2>;
+#if VTTS_X3_GEOM == 1
+template <int KS> using X128 = X128one<KS>;
+template <int KS> using X64 = X64one<KS>;
+template <int KS> using X32 = X32one<KS>;
+#elif VTTS_X3_GEOM == 2
+template <int KS> using X128 = X128two<KS>;
+template <int KS> using X64 = X64two<KS>;
+template <int KS> using X32 = X32two<KS>;
+#else
+template <int KS> using X128 = std::conditional_t<KS == 3, X128two<KS>, X128one<KS>>;
+template <int KS> using X64 = X64two<KS>;
+template <int KS> using X32 = std::conditional_t<KS == 3, X32one<KS>, X32two<KS>>;
+#endif
 
 template <class T>
 static hipError_t launch_x3(const PairArgsX3& p, hipStream_t s) {

@@ -10,7 +10,9 @@ MI355X through the HIP library instead of un-jitted XLA-CPU ops.
 Engine: the drop-in runs the **fp32** engine by default — the one that meets the reference's numerics (<= 1e-4 max-abs
 against the Haiku generator, BASELINE.json) at ~4e7 samples/s.  ``VTTS_MEL2WAVE_DTYPE=bf16`` in the environment (or
 ``FLAGS.dtype = "bf16"``) selects the bf16 throughput engine (~4e8 samples/s batched, max-abs ~1e-2 / 45 dB SNR against
-the same reference: bench.py ``parity_bf16``).
+the same reference: bench.py ``parity_bf16``); ``bf16x3`` the split-operand engine (the fp32 engine's layouts with the ResBlock
+convolutions on the bf16 matrix pipe, three bf16 products per term: ~8e-6 against the same reference — inside the 1e-4 bar — at
+~2.4x the fp32 engine's batched throughput: bench.py ``bf16x3_path``).
 
 Errors follow the reference: a missing config / checkpoint raises ``FileNotFoundError``; a wrong
 mel shape raises ``ValueError``.
@@ -45,8 +47,8 @@ def reload() -> None:
 
 def _engine_dtype() -> str:
     d = os.environ.get("VTTS_MEL2WAVE_DTYPE") or getattr(FLAGS, "dtype", None) or "f32"
-    if d not in ("f32", "bf16"):
-        raise ValueError(f"VTTS_MEL2WAVE_DTYPE / FLAGS.dtype must be 'f32' or 'bf16', got {d!r}")
+    if d not in ("f32", "bf16", "bf16x3"):
+        raise ValueError(f"VTTS_MEL2WAVE_DTYPE / FLAGS.dtype must be 'f32', 'bf16' or 'bf16x3', got {d!r}")
     return d
 
 
