@@ -226,7 +226,7 @@ def pmc_counters(kernel: str, args, B: int, T: int):
     return traffic, util, None
 
 
-def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=None, passes=3):
+def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=1, passes=3):
     """BASELINE.json configs[3]: n sentences cycled from the reference's demo transcript x the InfoRe lexicon (SURVEY.md §8d;
     fixtures tests/golden/text/, token ids pinned to the reference's own text2tokens) with synthetic checkpoints -> NAT
     duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) -> HiFi-GAN bf16 in
@@ -277,7 +277,7 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=
                # only the host's enqueue time of the acoustic model is separable; generator_ms then covers everything from there to the last sample
                # (0.0 = not applicable to the schedule this rank ran)
                "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3, "acoustic_enqueue_ms": tm.get("acoustic_enqueue_s", 0.0) * 1e3,
-               "overlap_groups": tm.get("overlap_groups", 1),
+               "overlap_groups": tm.get("overlap_groups", 1), "pinned_alloc_ms": tm.get("pinned_alloc_s", 0.0) * 1e3,
                "generator_ms": tm.get("generator_s", 0.0) * 1e3, "total_ms": total * 1e3}
     dm.close()
     am.close()
@@ -405,7 +405,7 @@ def main():
             if ok.item() < 1.0 and "error" not in pipe:
                 pipe = {"error": "another rank failed"}
         if n_gpus > 1 and "error" not in pipe:
-            keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "acoustic_enqueue_ms", "generator_ms", "total_ms", "frames_max", "overlap_groups"]
+            keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "acoustic_enqueue_ms", "generator_ms", "total_ms", "frames_max", "overlap_groups", "pinned_alloc_ms"]
             keys_sum = ["tokens", "frames", "samples"]
             tmax = torch.tensor([float(pipe[k]) for k in keys_max], dtype=torch.float64, device=dev)
             tsum = torch.tensor([float(pipe[k]) for k in keys_sum], dtype=torch.float64, device=dev)
@@ -418,6 +418,15 @@ def main():
         if "error" not in pipe:
             pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
             pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
+        if n_gpus == 1 and "error" not in pipe:
+            # the opt-in overlapped schedule (acoustic model and generator side by side, mel handed over in 6 groups), same process: what it gains
+            # depends on how the runtime maps the streams to hardware queues (viettts_amd/pipeline.py), so it is reported, not assumed
+            try:
+                po = pipeline_256(256, gen, info.rank, n_gpus, barrier, overlap_groups=6)
+                pipe["overlapped_schedule"] = {"overlap_groups": po["overlap_groups"], "total_ms": po["total_ms"], "generator_ms": po["generator_ms"],
+                                               "acoustic_enqueue_ms": po["acoustic_enqueue_ms"]}
+            except Exception as e:
+                pipe["overlapped_schedule"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- long-form (BASELINE configs[4]): 10 min of 16 kHz audio, exact 512-frame chunks + 13-frame halo, chunk c -> rank c mod N ----
     longform = None

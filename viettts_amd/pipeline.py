@@ -7,8 +7,8 @@ and keeps its waveforms.  The only collectives of the whole job are the three st
 (viettts_amd/dist.py).  Within a rank the stages run batched:
     tokens --DurationModel--> seconds/token --rules (text2mel.py:90-97)--> frames --AcousticModel--> mel --Generator--> wav
 with the generator fed ragged batches (sentences sorted by length, each batch padded to its longest; the bf16 engine
-gives every utterance the zero padding it would see alone and skips the tiles past its end), and the last two stages
-overlapped: the acoustic model hands its mel over in groups as the decoder finishes them (synthesize_sentences).
+gives every utterance the zero padding it would see alone and skips the tiles past its end); optionally the last two stages
+overlap: the acoustic model hands its mel over in groups as the decoder finishes them (synthesize_sentences, overlap_groups).
 """
 from __future__ import annotations
 
@@ -81,25 +81,28 @@ def _side_streams(device: torch.device):
     return _SIDE_STREAMS[key]
 
 
-OVERLAP_MIN_FRAMES = 16384  # below this a rank's shard is one small generator pass: nothing worth overlapping
-OVERLAP_GROUPS = 6  # 256 transcript sentences on one MI355X: 1 group 65.8 ms, 4 groups 65.1-65.4, 6 groups 63.8-63.9, 8 groups 64.6 (gpurun_out/r04_run1, r04_run6)
+OVERLAP_GROUPS = 6  # groups of the opt-in overlapped schedule (256 transcript sentences on one MI355X: 4 groups 65.1-65.4 ms, 6 groups 63.8-63.9, 8 groups 64.6)
 
 
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
                          dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 0,
-                         timing: Optional[dict] = None, overlap_groups: Optional[int] = None) -> Dict[int, np.ndarray]:
+                         timing: Optional[dict] = None, overlap_groups: Optional[int] = 1) -> Dict[int, np.ndarray]:
     """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index.  ``timing`` (a dict) receives
     wall seconds per stage.
 
-    **The acoustic model and the generator overlap (round 4).**  The decoder is a chain of ``max(frames)`` dependent steps of three short
-    launches each (latency-bound; it uses a fraction of the chip), the generator a few dozen chip-filling launches (power-bound).  The
-    sentences, sorted longest first, are cut into ``overlap_groups`` contiguous groups balanced by frames; the acoustic model runs on a
-    high-priority stream of its own and hands a group's mel over as soon as the decoder has produced the group's last frame
-    (include/vtts_nat.h: vtts_nat_acoustic_forward_groups — the postnet of that group on a side stream), and the generator consumes
-    the groups shortest first on the caller's stream, each group's waveforms leaving for pinned host memory on a copy stream as soon as
-    its pass ends.  Masks are seeded by the GLOBAL sentence index and every stage computes a row independently of its batch, so the
-    samples do not depend on the grouping (tests/test_gpu_nat.py).  ``overlap_groups``: None = by size (1 below OVERLAP_MIN_FRAMES
-    frames, else OVERLAP_GROUPS), 1 = the stages one after the other."""
+    **Schedules.**  ``overlap_groups = 1`` (the default): the stages one after the other on the caller's stream, the waveforms leaving for pinned
+    host memory on a copy stream.  ``overlap_groups = G > 1`` (opt-in, ``None`` = OVERLAP_GROUPS): the acoustic model and the generator overlap —
+    the decoder is a chain of ``max(frames)`` dependent steps of three short launches each (latency-bound; it uses a fraction of the chip), the
+    generator a few dozen chip-filling launches (power-bound).  The sentences, sorted longest first, are cut into G contiguous groups balanced
+    by frames; the acoustic model runs on a high-priority stream of its own and hands a group's mel over as soon as the decoder has produced the
+    group's last frame (include/vtts_nat.h: vtts_nat_acoustic_forward_groups — the postnet of that group on a side stream), and the generator
+    consumes the groups shortest first on the caller's stream.  Masks are seeded by the GLOBAL sentence index and every stage computes a row
+    independently of its batch, so the samples do not depend on the schedule (tests/test_gpu_nat.py: bit-identical to each sentence alone).
+    Why it is not the default (round 4, 256 transcript sentences on one MI355X): what the overlap gains is bounded by the sentences' length
+    spread — nothing is ready before the shortest group's last frame, ~200 of 281 steps in — and what it costs depends on how the runtime maps
+    the streams to hardware queues: 63.8 ms against 65.8 one after the other when the decoder's launches keep their priority, **86 ms** when
+    they queue behind the generator's workgroups (the same code after a large generator pass had created the engine's side streams first;
+    GPU_MAX_HW_QUEUES=2 restores 64.6: gpurun_out/r04 diag_bench_pipe).  A 3 % gain that can turn into a 30 % loss stays opt-in."""
     import time
 
     def mark(name, t_prev, sync=True):
@@ -131,9 +134,10 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     if ok:
         dev = generator.device
         ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
-        total_frames = int(sum(gfr.values()))
         if overlap_groups is None:
-            overlap_groups = OVERLAP_GROUPS if (ragged and total_frames >= OVERLAP_MIN_FRAMES) else 1
+            overlap_groups = OVERLAP_GROUPS
+        if not ragged:
+            overlap_groups = 1
         bounds = _overlap_groups([nfr[k] for k in ok], overlap_groups if hasattr(acoustic_model, "wait_group") else 1)
         ngroups = len(bounds) - 1
         cur = torch.cuda.current_stream(dev)
@@ -168,7 +172,10 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
                 # pinned, on a copy stream: the next pass computes while this one's samples leave
                 done = torch.cuda.Event()
                 done.record(cur)
+                t_pin = time.perf_counter()
                 host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
+                if timing is not None:
+                    timing["pinned_alloc_s"] = timing.get("pinned_alloc_s", 0.0) + time.perf_counter() - t_pin  # ~0 when the caching host allocator has a block
                 if os.environ.get("VTTS_PIPE_COPY_ON_CUR"):  # diagnostic switch: the read-back on the generator's own stream
                     host.copy_(w, non_blocking=True)
                 else:
