@@ -77,6 +77,27 @@ def test_x3_pair_kat(gen, v1_params, dev, pair, capsys):
     assert rel < 3e-5, (err, rel)
 
 
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+@pytest.mark.parametrize("L", [37, 300])
+def test_x3_upsample_kat(gen, v1_params, dev, i, L, capsys):
+    """The four transposed convolutions with split operands (convt_x3_k) against the oracle's ``conv1d_transpose(lrelu(x, 0.1))`` in fp64
+    (vietTTS/hifigan/model.py:112-114; lax "SAME"): ragged lengths, several tiles and the utterance edges."""
+    spec = [s for s in conv_specs(V1) if s.key == f"generator/~/ups_{i}"][0]
+    rng = np.random.default_rng(40 + i)
+    B = 2
+    x = rng.standard_normal((B, spec.cin, L)).astype(np.float32) * 2.0
+    w, b = v1_params[spec.key]["w"], v1_params[spec.key]["b"]
+    ref = orc.conv1d_transpose(orc.leaky_relu(_nwc(x).astype(np.float64), 0.1), w.astype(np.float64), b.astype(np.float64), spec.stride)
+    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 0.1)
+    torch.cuda.synchronize()
+    assert y.shape == (B, spec.cout, L * spec.stride)
+    err = float(np.abs(_nwc(y.cpu().numpy()) - ref).max())
+    rel = err / float(np.abs(ref).max())
+    with capsys.disabled():
+        print(f"\n[bf16x3 ups_{i} L={L}] max|err| {err:.3e} ({rel:.2e} of max|ref| {np.abs(ref).max():.2f})")
+    assert rel < 3e-5, (err, rel)
+
+
 @pytest.mark.parametrize("case", ["v1_scaled_T8", "v1_scaled_T37", "v1_scaled_T512"])
 def test_x3_generator_vs_reference_golden(golden_dir, gen, dev, case, capsys):
     """Whole generator against the reference generator's own fp64 output (tests/golden, minted by oracle/make_golden.py from

@@ -334,6 +334,15 @@ int build_layers(vtts_hifigan* h) {
             off = align_up(off + l.wp_floats * sizeof(float), 256);
         }
     }
+    if (h->x3) {
+        for (int i : h->idx_ups) {
+            Layer& l = h->layers[i];
+            if (!convt_x3_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, 4)) continue;
+            l.has_x3 = true;
+            l.off_x3 = off;
+            off = align_up(off + convt_x3_bytes(l.cin, l.cout, l.stride), 256);
+        }
+    }
     if (h->x3 && h->cfg.resblock != 2) {
         for (size_t r = 0; r < h->idx_res.size(); ++r)
             for (int q = 0; q < 6; ++q) {
@@ -407,7 +416,10 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
     const bool ncw = x.st == 1 && x.sc == L && (x.sb % 4) == 0;
     const bool want_mfma = h->opt_kernels == 0 && l.has_wp;
     if (l.kind == KIND_CONVT) {
-        if (want_mfma && ncw && !res && acc_mode == ACC_STORE && convT1d_f32_mfma_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, L))
+        if (h->x3 && l.has_x3 && h->opt_kernels == 0 && h->opt_fuse >= 1 && ncw && !res && acc_mode == ACC_STORE) {
+            a.wp = h->blob + l.off_x3;  // VTTS_BF16X3: the transposed convolutions on the bf16 matrix pipe with split operands too (kernels_x3.hip)
+            e = launch_convt_x3(a, s);
+        } else if (want_mfma && ncw && !res && acc_mode == ACC_STORE && convT1d_f32_mfma_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, L))
             e = launch_convT1d_f32_mfma(a, s);
         else
             e = launch_convT1d_generic(a, s);
@@ -1309,7 +1321,8 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
         if (h->dtype == VTTS_BF16) break;
         memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
         memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
-        if (l.has_x3) pair_x3_pack(l.w.data(), l.cin, l.k, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
+        if (l.has_x3 && l.kind == KIND_CONVT) convt_x3_pack(l.w.data(), l.cin, l.cout, l.k, l.stride, l.pad_a, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
+        else if (l.has_x3) pair_x3_pack(l.w.data(), l.cin, l.k, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
         if (l.has_wp && l.kind == KIND_CONV)
             conv1d_f32_mfma_pack(l.w.data(), l.cin, l.cout, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));
         else if (l.has_wp)

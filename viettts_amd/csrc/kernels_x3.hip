@@ -428,4 +428,260 @@ hipError_t launch_pair_x3(const ConvArgs& a, const void* w1, const void* w2, con
     return hipErrorInvalidValue;
 }
 
+
+// =====================================================================================================
+// The four transposed convolutions (model.py:112-114: x = ups_i(leaky_relu(x, 0.1))) with split operands, polyphase form (k = 2 * stride;
+// kernels_f32_mfma.hip: output p = s q + r of group g = r / (s/2) reads input frames q + g - 1 + m, m = 0, 1, through tap
+// j = s (g - 1 + m) + pad_a - r): per group a GEMM  Y_g[m' = co * SH + ph, q] = sum_{m, ci} W_g[m'][(m, ci)] lrelu(x)[ci][q + g - 1 + m].
+// Same staging as the pair kernel (fp32 channel-major in, hi / lo channels-last tiles of N1 + 2 frames); a wave owns one 32-row block of m' in BOTH
+// groups (m-block index = group), so the three distinct B fragments (frames q - 1, q, q + 1) are read once per k-step and, in the accumulator layout,
+// a lane ends up with consecutive output samples of one channel: SH = 4 -> a float4 per group (16 contiguous bytes of y[co][8 q + 4 g ..]),
+// SH = 1 -> a float2 of both groups (y[co][2 q], y[co][2 q + 1]).  fp32 in HBM on both sides, as everything outside the matrix products.
+// =====================================================================================================
+template <int CIN_, int COUT_, int SH_, int N1_, int WM_, int WN_>
+struct UXTile {
+    static constexpr int CIN = CIN_, COUT = COUT_, SH = SH_, S = 2 * SH_, N1 = N1_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = 64 * WM * WN, NWAVES = WM * WN;
+    static constexpr int MPG = COUT * SH;              // GEMM rows per group
+    static constexpr int MT = WM * 32;                 // m' rows per workgroup (per group)
+    static constexpr int NR = N1 / WN / 32;
+    static constexpr int SPR = CIN / 8, P = CIN * 2, KSTEPS = CIN / 16, MB = MPG / 32;
+    static constexpr int ROWS = N1 + 2;                // frames t0 - 1 .. t0 + N1
+    static constexpr int PLANE = tile_rows16(ROWS) * P;
+    static constexpr int LDS_BYTES = 2 * PLANE;
+    static constexpr size_t PLANE_W = (size_t)4 * KSTEPS * MB * 1024;  // bytes of one weight plane: [g][m][ks][mblk][lane][8]
+    static_assert(MPG % MT == 0 && N1 % (WN * 32) == 0 && (SH == 4 || SH == 1) && KSTEPS % 2 == 0, "tiling");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <class T>
+__global__ __launch_bounds__(T::THREADS, 2) void convt_x3_k(ConvArgs a) {
+    constexpr int CIN = T::CIN, COUT = T::COUT, SH = T::SH, S = T::S, N1 = T::N1, WN = T::WN, NR = T::NR;
+    constexpr int SPR = T::SPR, KSTEPS = T::KSTEPS, MB = T::MB, NWAVES = T::NWAVES, ROWS = T::ROWS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const thi = lds;
+    unsigned char* const tlo = lds + T::PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lh = lane >> 5;
+    const int L = a.L, Lout = a.Lout;
+    const int t0 = blockIdx.x * N1;  // first input frame of this workgroup
+    if (t0 >= L) return;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int mblk = blockIdx.y * T::WM + wm;  // this wave's 32-row block of m' (in both groups)
+    const float* __restrict__ xb = a.x + (long)b * CIN * L;
+    const float slope = a.slope_in;
+    auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
+        hi = pack_bf16x2(v0, v1);
+        lo = pack_bf16x2(v0 - bf16_lo(hi), v1 - bf16_hi(hi));
+    };
+    // ---- input tile: frames t0 - 1 .. t0 + N1 (zero outside the utterance: lax "SAME"), lane <-> frame, 8 channels per unit ----
+    {
+        constexpr int NBLK = (ROWS + 63) / 64, UNITS = NBLK * SPR, UB = 4;
+        for (int u0 = wave * UB; u0 < UNITS; u0 += NWAVES * UB) {
+            float v[UB][8];
+            int row[UB], slot[UB];
+            bool live[UB];
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                const int u = u0 + q < UNITS ? u0 + q : UNITS - 1;
+                live[q] = u0 + q < UNITS;
+                slot[q] = u % SPR;
+                row[q] = (u / SPR) * 64 + lane;
+                const int t = t0 - 1 + row[q];
+                const bool ok = live[q] && row[q] < ROWS && t >= 0 && t < L;
+                const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+                const float* __restrict__ g = xb + (long)(slot[q] * 8) * L + tc;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * L];
+                if (!ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[q][e] = 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < UB; ++q) {
+                if (!live[q] || row[q] >= ROWS) continue;
+                uint4 h4, l4;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[q][e] = lrelu(v[q][e], slope);
+                split2(v[q][0], v[q][1], h4.x, l4.x);
+                split2(v[q][2], v[q][3], h4.y, l4.y);
+                split2(v[q][4], v[q][5], h4.z, l4.z);
+                split2(v[q][6], v[q][7], h4.w, l4.w);
+                const int off = tile_off<SPR>(row[q], slot[q]);
+                *reinterpret_cast<uint4*>(thi + off) = h4;
+                *reinterpret_cast<uint4*>(tlo + off) = l4;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA loop over the k-steps: A fragment (plane, g, m, ks): a.wp + plane*PLANE_W + ((((g*2 + m)*KSTEPS + ks)*MB + mblk)*64 + lane)*16 ----
+    f32x16 acc[2][NR];  // [group][column block]
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][nr][r] = 0.0f;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, (int)(2 * T::PLANE_W), 0x00020000);
+    const unsigned a_voff = (unsigned)(mblk * 64 + lane) * 16;
+    bf16x8 af[2][4][2], bf[2][3][NR][2];  // A: [ring slot][g*2 + m][plane]; B: [parity][frame offset f][column block][plane]
+    auto load_a = [&](int ks, int slot) {
+        const int kc = ks < KSTEPS ? ks : KSTEPS - 1;
+#pragma unroll
+        for (int gm = 0; gm < 4; ++gm) {
+            const int soff = ((gm * KSTEPS + kc) * MB) * 1024;
+            af[slot][gm][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff, soff, 0));
+            af[slot][gm][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff, soff + (int)T::PLANE_W, 0));
+        }
+    };
+    const int rowbase0 = wn * (N1 / WN) + l31;  // tile row of frame q - 1 for this lane's column q of block 0
+    auto load_b = [&](int ks, int par) {
+        const int kc = ks < KSTEPS ? ks : KSTEPS - 1;
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int off = tile_off<SPR>(rowbase0 + f + nr * 32, kc * 2 + lh);
+                bf[par][f][nr][0] = *reinterpret_cast<const bf16x8*>(thi + off);
+                bf[par][f][nr][1] = *reinterpret_cast<const bf16x8*>(tlo + off);
+            }
+    };
+    load_a(0, 0);
+    load_b(0, 0);
+#pragma unroll 1
+    for (int ks0 = 0; ks0 < KSTEPS; ks0 += 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            load_a(ks0 + i + 1, (i + 1) & 1);
+            load_b(ks0 + i + 1, (i + 1) & 1);
+            const int sl = i & 1;
+            // group g, tap m reads frame offset f = g + m; small terms first
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int gm = 0; gm < 4; ++gm)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr) {
+                        const int g = gm >> 1, f = g + (gm & 1);
+                        const int pa = term == 0 ? 1 : 0, pb = term == 1 ? 1 : 0;
+                        acc[g][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][gm][pa], bf[sl][f][nr][pb], acc[g][nr], 0, 0, 0);
+                    }
+            constexpr int NMF = 12 * NR, NA = 8, NB = 6 * NR;
+            int done = 0;
+#pragma unroll
+            for (int m = 0; m < NMF; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                const int upto = (m + 1) * (NA + NB) / NMF;
+                for (; done < upto; ++done) {
+                    if (done < NA) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: + bias, fp32 stores of consecutive output samples of one channel ----
+    float* yb = a.y + (long)b * COUT * Lout;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr) {
+        const int q = t0 + wn * (N1 / WN) + nr * 32 + l31;
+        if (q >= L) continue;
+        if constexpr (SH == 4) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int co = mblk * 8 + 2 * rq + lh;  // rows 8 rq + 4 lh + i of the block = (co, ph = i)
+                    const float bv = a.bias[co];
+                    const float4 o = make_float4(acc[g][nr][4 * rq + 0] + bv, acc[g][nr][4 * rq + 1] + bv, acc[g][nr][4 * rq + 2] + bv, acc[g][nr][4 * rq + 3] + bv);
+                    *reinterpret_cast<float4*>(yb + (long)co * Lout + (long)S * q + 4 * g) = o;
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float bv = a.bias[co];
+                *reinterpret_cast<float2*>(yb + (long)co * Lout + 2l * q) = make_float2(acc[0][nr][r] + bv, acc[1][nr][r] + bv);
+            }
+        }
+    }
+}
+
+//                                      CIN COUT SH  N1  WM WN
+using UX0 = UXTile<512, 256, 4, 64, 8, 1>;
+using UX1 = UXTile<256, 128, 4, 128, 4, 2>;
+using UX2 = UXTile<128, 64, 1, 256, 2, 4>;
+using UX3 = UXTile<64, 32, 1, 512, 1, 8>;
+
+static int convt_x3_class(int Cin, int Cout, int K, int stride) {
+    if (Cin == 512 && Cout == 256 && K == 16 && stride == 8) return 0;
+    if (Cin == 256 && Cout == 128 && K == 16 && stride == 8) return 1;
+    if (Cin == 128 && Cout == 64 && K == 4 && stride == 2) return 2;
+    if (Cin == 64 && Cout == 32 && K == 4 && stride == 2) return 3;
+    return -1;
+}
+bool convt_x3_supported(int Cin, int Cout, int K, int stride, int pad_a, int L) {
+    if (convt_x3_class(Cin, Cout, K, stride) < 0 || L < 1) return false;
+    for (int r = 0; r < stride; ++r) {  // the (q-1, q) / (q, q+1) polyphase split: every phase's two taps must exist
+        const int g = r / (stride / 2);
+        for (int m = 0; m < 2; ++m) {
+            const int j = stride * (g - 1 + m) + pad_a - r;
+            if (j < 0 || j >= K) return false;
+        }
+    }
+    return true;
+}
+size_t convt_x3_bytes(int Cin, int Cout, int stride) { return 2 * (size_t)4 * (Cin / 16) * (Cout * (stride / 2) / 32) * 1024; }
+
+// Haiku [K][Cout][Cin] fp32 -> [plane][g][m][ks][mblk][lane][8] bf16: row m' = mblk*32 + (lane & 31) = co*SH + ph, k = ks*16 + 8*(lane >> 5) + e = ci
+void convt_x3_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, unsigned short* out) {
+    const int SH = stride / 2, MB = Cout * SH / 32, KSTEPS = Cin / 16;
+    const size_t plane = (size_t)4 * KSTEPS * MB * 512;  // elements
+    for (int gm = 0; gm < 4; ++gm)
+        for (int ks = 0; ks < KSTEPS; ++ks)
+            for (int mb = 0; mb < MB; ++mb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int mp = mb * 32 + (lane & 31), co = mp / SH, ph = mp % SH, g = gm >> 1, m = gm & 1;
+                        const int ci = ks * 16 + 8 * (lane >> 5) + e;
+                        const int j = stride * (g - 1 + m) + pad_a - (g * SH + ph);
+                        const float w = w_hk[((size_t)j * Cout + co) * Cin + ci];
+                        unsigned u;
+                        memcpy(&u, &w, 4);
+                        const unsigned uh = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+                        float hi;
+                        memcpy(&hi, &uh, 4);
+                        const float lo = w - hi;
+                        unsigned ul;
+                        memcpy(&ul, &lo, 4);
+                        ul = (ul + 0x7fffu + ((ul >> 16) & 1u)) >> 16;
+                        const size_t o = ((((size_t)gm * KSTEPS + ks) * MB + mb) * 64 + lane) * 8 + e;
+                        out[o] = (unsigned short)(uh >> 16);
+                        out[plane + o] = (unsigned short)ul;
+                    }
+}
+
+template <class T>
+static hipError_t launch_ux(const ConvArgs& a, hipStream_t s) {
+    static DynLdsOnce once;
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&convt_x3_k<T>), T::LDS_BYTES, once); e != hipSuccess) return e;
+    dim3 grid((a.L + T::N1 - 1) / T::N1, T::MPG / T::MT, a.B);
+    hipLaunchKernelGGL(convt_x3_k<T>, grid, dim3(T::THREADS), T::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
+// a.x [B][Cin][L] fp32, a.y [B][Cout][stride*L], a.wp = convt_x3_pack, a.bias [Cout], a.slope_in = the LeakyReLU on the input
+hipError_t launch_convt_x3(const ConvArgs& a, hipStream_t s) {
+    switch (convt_x3_class(a.Cin, a.Cout, a.K, a.stride)) {
+        case 0: return launch_ux<UX0>(a, s);
+        case 1: return launch_ux<UX1>(a, s);
+        case 2: return launch_ux<UX2>(a, s);
+        case 3: return launch_ux<UX3>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 }  // namespace vtts

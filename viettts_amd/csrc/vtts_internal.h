@@ -84,6 +84,11 @@ bool pair_x3_supported(int C, int K, int dil, int L);
 size_t pair_x3_conv_bytes(int C, int K);
 void pair_x3_pack(const float* w_hk, int C, int K, unsigned short* out);
 hipError_t launch_pair_x3(const ConvArgs& a, const void* w1, const void* w2, const float* bias2, hipStream_t s);
+// ... and the four transposed convolutions (polyphase, k = 2 * stride): a.x [B][Cin][L] -> a.y [B][Cout][stride * L], a.wp = convt_x3_pack's output
+bool convt_x3_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
+size_t convt_x3_bytes(int Cin, int Cout, int stride);
+void convt_x3_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, unsigned short* out);
+hipError_t launch_convt_x3(const ConvArgs& a, hipStream_t s);
 
 // ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
 bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
