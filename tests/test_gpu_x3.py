@@ -152,3 +152,21 @@ def test_x3_edge_lengths_and_microbatches(gen, v1_params, dev):
     f32 = gen(mel).clone()
     gen.set_option("fuse", 2)
     assert not torch.equal(f32, base) and float((f32 - base).abs().max()) < BOUND
+
+
+def test_x3_other_architectures_run_on_the_fp32_kernels(dev):
+    """Shapes the split kernels do not cover (the TINY fixtures' channel counts, ResBlock2 generators) run on the fp32 engine's kernels under the
+    same handle type: bit-identical to an fp32 handle."""
+    from viettts_amd.hifigan.config import TINY, TINY2
+    from viettts_amd.hifigan.generator import Generator
+
+    for cfg in (TINY, TINY2):
+        params = synthetic_params(cfg, 4321, "scaled")
+        mel = torch.from_numpy(synthetic_mel(2, 12, 1234)).to(dev)
+        outs = []
+        for dt in ("f32", "bf16x3"):
+            g = Generator(cfg, device=dev, dtype=dt)
+            g.load_params(params)
+            outs.append(g(mel).clone())
+            g.close()
+        assert torch.equal(outs[0], outs[1])
