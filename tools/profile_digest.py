@@ -54,7 +54,7 @@ def main():
         stats[k] = {"calls": n, "avg_us_all": sum(v) / n / 1e3, "avg_us_timed": sum(timed) / len(timed) / 1e3, "timed_calls": len(timed)}
     tot = sum(s["avg_us_timed"] * s["timed_calls"] for s in stats.values())
     with open(os.path.join(run, f"{tag}{sfx}_kernel_stats.md"), "w") as f:
-        f.write(f"# {tag} — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32{' --dtype f32' if dt == 'f32' else ''}` ({dt}, B=64 x T=1024); "
+        f.write(f"# {tag} — `rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32 --streams 1 --microbatch 64{'' if dt == 'bf16' else ' --dtype ' + dt}` ({dt}, B=64 x T=1024; one stream: the schedule of bench.py's roofline calibration pass); "
                 f"source digest `{_digest()[:16]}`.  avg (timed) drops each kernel's warm-up-pass launches (first touch of the workspace).\n\n")
         f.write("| kernel | calls | avg us (all) | avg us (timed passes) | % of timed GPU time |\n|---|---:|---:|---:|---:|\n")
         for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["avg_us_timed"] * kv[1]["timed_calls"]):
@@ -110,7 +110,7 @@ def main():
     out = {
         "source_digest": _digest(),
         "tag": tag,
-        "command": f"python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32{' --dtype f32' if dt == 'f32' else ''}  ({dt}, B=64 x T=1024; kernel-trace pass + --pmc passes, tools/profile_final.sh)",
+        "command": f"python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32 --streams 1 --microbatch 64{'' if dt == 'bf16' else ' --dtype ' + dt}  ({dt}, B=64 x T=1024; kernel-trace pass + --pmc passes, tools/profile_final.sh)",
         "time_weighted_mfma_util_resblock_kernels": tw,
         "kernels": kern,
     }

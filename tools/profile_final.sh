@@ -22,12 +22,19 @@ for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
   timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $O/pmc/p$i -- $BENCH > $O/pmc_p$i.log 2>&1
 done
 # the fp32 (1e-4 parity) engine at the same shape: durations + the SQ set (its kernels write exactly the algorithmic bytes: profiles/r01_b_pmc_f32.md)
-BENCH32="python $R/bench.py --dtype f32 --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-rtf"  # one stream: a kernel's duration and counters are its own (the engine's default runs two half-size passes side by side)
+BENCH32="python $R/bench.py --dtype f32 --streams 1 --microbatch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-rtf"  # one stream: a kernel's duration and counters are its own (the engine's default runs two half-size passes side by side)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_f32 -o r -- $BENCH32 > $O/trace_f32.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_f32/p1 -- $BENCH32 > $O/pmc_f32_p1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f32/p2 -- $BENCH32 > $O/pmc_f32_p2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_f32/p3 -- $BENCH32 > $O/pmc_f32_p3.log 2>&1
+# the split-operand engine (VTTS_BF16X3) at the same shape, same schedule
+BENCHX3="python $R/bench.py --dtype bf16x3 --streams 1 --microbatch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-rtf"
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_bf16x3 -o r -- $BENCHX3 > $O/trace_bf16x3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_bf16x3/p1 -- $BENCHX3 > $O/pmc_bf16x3_p1.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_bf16x3/p2 -- $BENCHX3 > $O/pmc_bf16x3_p2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_bf16x3/p3 -- $BENCHX3 > $O/pmc_bf16x3_p3.log 2>&1
 cd $R
 python tools/profile_digest.py $O $T
 python tools/profile_digest.py $O $T f32
+python tools/profile_digest.py $O $T bf16x3
 find $O -name "*.csv" -size +5M -delete; find $O -name "*.db" -size +20M -delete

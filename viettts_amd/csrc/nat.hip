@@ -311,26 +311,31 @@ __global__ __launch_bounds__(256) void nat_conv_bn_act_k(const float* __restrict
     }
 }
 
-// Postnet convolutions (model.py:113-121) on the fp32 matrix cores: y = act(batchnorm_eval(conv1d_same(x))) [+ res],
-// channels-last fp32 rows, same zero-beyond-the-length semantics as nat_conv_bn_act_k.  GEMM view: M = cout (A = weights,
-// host-packed [mblk][32-channel step][tap][lane][16]: element i of lane = W[tap][32*cs + 16*(lane/32) + i][32*mblk + lane%32]),
-// N = frame, k = (32-channel step, tap, channel): for one step a lane reads 64 contiguous bytes of its frame's row, the
-// other half-wave the next 64, so every 128-byte line fetched is used in full and the (64 + K - 1)-row window of a step
-// stays in L1 across the taps.  A wave owns MR x 2 accumulator blocks (32 couts x 32 frames each); no LDS, no barrier:
-// latency is covered by several workgroups per CU.
+// Postnet convolutions (model.py:113-121) and the hoisted gate GEMMs on the fp32 matrix cores: y = act(batchnorm_eval(conv1d_same(x))) [+ res],
+// channels-last fp32 rows, same zero-beyond-the-length semantics as nat_conv_bn_act_k.  GEMM view: M = cout (A = weights, host-packed
+// [mblk][32-channel step][tap][lane][16]: element i of lane = W[tap][32*cs + 16*(lane/32) + i][32*mblk + lane%32]), N = frame,
+// k = (32-channel step, tap, channel).  A workgroup = 64 frames x (4 waves x MR m-blocks); a wave owns MR x 2 accumulator blocks.
+// Round 4: the B operand goes through LDS.  Round 1-3 had every lane read 64 contiguous bytes of ITS frame's row per step and tap straight
+// from L1 (no LDS, no barrier): 64 lanes x 16 bytes from 32 different rows per instruction, five times over for the five taps — the kernel
+// sat at 64-80 TF/s, bound by the vector-memory pipeline (software-pipelining those loads changed nothing: profiles/r04_c_kernel_structure_findings.md).
+// Now the 64 + K - 1 rows x 32 channels of a step are staged ONCE (coalesced float4 loads along the channels, next step's in flight under this
+// step's MFMAs, two LDS buffers, one barrier per step), the taps are shifted views of the tile, and a fragment is one ds_read_b32 per lane
+// (row stride 33 floats: 32 consecutive frames of one channel hit 32 banks).  The fmaf chains are the old ones, in the old order: same bits.
 template <int K, int MR>
 __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__ x, const int* __restrict__ lengths, const float4* __restrict__ wpk,
                                                        const float* __restrict__ bias, const float* __restrict__ inv, const float* __restrict__ mean,
                                                        const float* __restrict__ offset, const float* __restrict__ res, float* __restrict__ y, int Lmax,
                                                        int Cin, int Cout, int act, int tile0) {
     typedef float f32x16 __attribute__((ext_vector_type(16)));
-    constexpr int NR = 2, PL = (K - 1) / 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    constexpr int NR = 2, PL = (K - 1) / 2, ROWS = 64 + K - 1, RS = 33, UNITS = ROWS * 8, UPT = (UNITS + 255) / 256;
+    __shared__ float xs[2][ROWS * RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int b = blockIdx.z, t0 = (blockIdx.x + tile0) * 64;  // tile0: a launch may cover the 64-frame tiles [tile0, tile0 + gridDim.x) only
     const int len = lengths[b];
     const int MB = (Cout + 31) / 32, NCS = (Cin + 31) / 32;
     const int mb0 = (blockIdx.y * 4 + wave) * MR;
-    if (t0 >= len || mb0 >= MB) return;  // rows at or past the length: zero by the caller's memset (last layer) or masked by the reader
+    if (t0 >= len) return;               // rows at or past the length: zero by the caller's memset (last layer) or masked by the reader (uniform per workgroup)
+    const bool mine = mb0 < MB;          // a wave without an m-block still helps staging and meets the barriers
     const bool two = len - t0 > 32;      // a sentence's last tile with <= 32 frames left: the second 32-frame block is skipped (uniform)
     f32x16 acc[MR][NR];
 #pragma unroll
@@ -345,56 +350,72 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
                 for (int nr = 0; nr < NR; ++nr) acc[mr][nr][4 * rq + i] = bv;
             }
     const float* __restrict__ xb = x + (size_t)b * Lmax * Cin;
+    // staging of step cs: unit u = (row, 4-channel group); unconditional loads from clamped addresses, masked afterwards
+    float4 sv[UPT];
+    auto stage_load = [&](int cs) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = tid + q * 256, uc = u < UNITS ? u : UNITS - 1;
+            const int row = uc >> 3, c = cs * 32 + 4 * (uc & 7);
+            const int t = t0 + row - PL;
+            const int tc = t < 0 ? 0 : (t >= len ? len - 1 : t);
+            const int cc = c + 4 <= Cin ? c : Cin - 4;
+            float4 v = *reinterpret_cast<const float4*>(xb + (size_t)tc * Cin + cc);
+            if (t != tc || c != cc) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            sv[q] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = tid + q * 256;
+            if (u >= UNITS) continue;
+            float* d = &xs[buf][(u >> 3) * RS + 4 * (u & 7)];
+            d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
     for (int cs = 0; cs < NCS; ++cs) {
+        const int buf = cs & 1;
+        if (cs + 1 < NCS) stage_load(cs + 1);  // in flight under this step's MFMAs
+        if (mine) {
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            float4 av[MR][4], bv[NR][4];
+            for (int j = 0; j < K; ++j) {
+                float4 av[MR][4];
 #pragma unroll
-            for (int mr = 0; mr < MR; ++mr) {
-                const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;  // a wave's spare block re-reads the last one; never stored
-                const float4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 64 + lane) * 4;
+                for (int mr = 0; mr < MR; ++mr) {
+                    const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;  // a wave's spare block re-reads the last one; never stored
+                    const float4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 64 + lane) * 4;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) av[mr][q] = ap[q];
-            }
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr) {
-                if (nr == 1 && !two) continue;
-                const int t = t0 + nr * 32 + l31 + j - PL;
-                const int tc = t < 0 ? 0 : (t >= len ? len - 1 : t);  // unconditional loads from clamped addresses, masked afterwards
+                    for (int q = 0; q < 4; ++q) av[mr][q] = ap[q];
+                }
+                const float* xr = &xs[buf][(l31 + j) * RS + 16 * lh];  // tile row of frame t0 + l31 + j - PL, this half-wave's 16 channels
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int c = cs * 32 + 16 * lh + 4 * q;
-                    const int cc = c + 4 <= Cin ? c : Cin - 4;
-                    float4 v = *reinterpret_cast<const float4*>(xb + (size_t)tc * Cin + cc);
-                    if (t != tc || c != cc) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    bv[nr][q] = v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float bv[NR];
+#pragma unroll
+                        for (int nr = 0; nr < NR; ++nr) bv[nr] = (nr == 0 || two) ? xr[nr * 32 * RS + 4 * q + e] : 0.0f;
+#pragma unroll
+                        for (int mr = 0; mr < MR; ++mr) {
+                            const float a1 = e == 0 ? av[mr][q].x : e == 1 ? av[mr][q].y : e == 2 ? av[mr][q].z : av[mr][q].w;
+#pragma unroll
+                            for (int nr = 0; nr < NR; ++nr)
+                                if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nr], acc[mr][nr], 0, 0, 0);
+                        }
+                    }
                 }
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].x, bv[nr][q].x, acc[mr][nr], 0, 0, 0);
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].y, bv[nr][q].y, acc[mr][nr], 0, 0, 0);
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].z, bv[nr][q].z, acc[mr][nr], 0, 0, 0);
-#pragma unroll
-                for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-                    for (int nr = 0; nr < NR; ++nr)
-                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mr][q].w, bv[nr][q].w, acc[mr][nr], 0, 0, 0);
-            }
+        }
+        if (cs + 1 < NCS) {
+            stage_store(buf ^ 1);  // nobody reads that buffer any more: its last readers passed the barrier that ended step cs - 1
+            __syncthreads();
         }
     }
+    if (!mine) return;
     const bool bn = inv != nullptr;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
