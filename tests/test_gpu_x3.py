@@ -170,3 +170,30 @@ def test_x3_other_architectures_run_on_the_fp32_kernels(dev):
             outs.append(g(mel).clone())
             g.close()
         assert torch.equal(outs[0], outs[1])
+
+
+def test_mel2wave_dropin_on_the_split_engine(tmp_path, monkeypatch, v1_params):
+    """``VTTS_MEL2WAVE_DTYPE=bf16x3``: the reference's ``mel2wave(mel)`` surface (vietTTS/hifigan/mel2wave.py:20-41) on the split-operand engine —
+    same files read, same return type, inside the reference's 1e-4."""
+    import os
+
+    from viettts_amd.hifigan import mel2wave as m2w
+    from viettts_amd.hifigan.weights import save_haiku_pickle
+
+    (tmp_path / "assets/hifigan").mkdir(parents=True)
+    (tmp_path / "assets/infore/hifigan").mkdir(parents=True)
+    repo_cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets/hifigan/config.json")
+    (tmp_path / "assets/hifigan/config.json").write_text(open(repo_cfg).read())
+    save_haiku_pickle(tmp_path / "assets/infore/hifigan/hk_hifi.pickle", v1_params)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("VTTS_MEL2WAVE_DTYPE", "bf16x3")
+    m2w.reload()
+    try:
+        mel = synthetic_mel(1, 40, 2)
+        wav = m2w.mel2wave(mel)
+        assert isinstance(wav, np.ndarray) and wav.dtype == np.float32 and wav.shape == (10240,)
+        assert m2w._generator().dtype_name == "bf16x3"
+        want = orc.mel2wave_oracle(v1_params, mel, V1)
+        assert np.abs(wav - want).max() < BOUND
+    finally:
+        m2w.reload()

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void nat_conv_bn_act_k(const float* __restrict
 // step's MFMAs, two LDS buffers, one barrier per step), the taps are shifted views of the tile, and a fragment is one ds_read_b32 per lane
 // (row stride 33 floats: 32 consecutive frames of one channel hit 32 banks).  The fmaf chains are the old ones, in the old order: same bits.
 template <int K, int MR>
-__global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__ x, const int* __restrict__ lengths, const float4* __restrict__ wpk,
+__global__ __launch_bounds__(256, 2) void nat_conv_mfma_k(const float* __restrict__ x, const int* __restrict__ lengths, const float4* __restrict__ wpk,
                                                        const float* __restrict__ bias, const float* __restrict__ inv, const float* __restrict__ mean,
                                                        const float* __restrict__ offset, const float* __restrict__ res, float* __restrict__ y, int Lmax,
                                                        int Cin, int Cout, int act, int tile0) {
@@ -374,45 +374,70 @@ __global__ __launch_bounds__(256) void nat_conv_mfma_k(const float* __restrict__
             d[0] = sv[q].x; d[1] = sv[q].y; d[2] = sv[q].z; d[3] = sv[q].w;
         }
     };
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int cs = 0; cs < NCS; ++cs) {
-        const int buf = cs & 1;
-        if (cs + 1 < NCS) stage_load(cs + 1);  // in flight under this step's MFMAs
-        if (mine) {
+    // A operands (weights, L2-resident) one (step, tap) ahead in a second register set: with two workgroups per CU nothing else covers their round trip
+    auto load_a = [&](int cs, int j, float4 (&av)[MR][4]) {
 #pragma unroll
-            for (int j = 0; j < K; ++j) {
-                float4 av[MR][4];
+        for (int mr = 0; mr < MR; ++mr) {
+            const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;  // a wave's spare block re-reads the last one; never stored
+            const float4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 64 + lane) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[mr][q] = ap[q];
+        }
+    };
+    auto mfma_tap = [&](int buf, int j, const float4 (&av)[MR][4]) {
+        const float* xr = &xs[buf][(l31 + j) * RS + 16 * lh];  // tile row of frame t0 + l31 + j - PL, this half-wave's 16 channels
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv[NR];
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) bv[nr] = (nr == 0 || two) ? xr[nr * 32 * RS + 4 * q + e] : 0.0f;
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr) {
-                    const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;  // a wave's spare block re-reads the last one; never stored
-                    const float4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 64 + lane) * 4;
+                    const float a1 = e == 0 ? av[mr][q].x : e == 1 ? av[mr][q].y : e == 2 ? av[mr][q].z : av[mr][q].w;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) av[mr][q] = ap[q];
-                }
-                const float* xr = &xs[buf][(l31 + j) * RS + 16 * lh];  // tile row of frame t0 + l31 + j - PL, this half-wave's 16 channels
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float bv[NR];
-#pragma unroll
-                        for (int nr = 0; nr < NR; ++nr) bv[nr] = (nr == 0 || two) ? xr[nr * 32 * RS + 4 * q + e] : 0.0f;
-#pragma unroll
-                        for (int mr = 0; mr < MR; ++mr) {
-                            const float a1 = e == 0 ? av[mr][q].x : e == 1 ? av[mr][q].y : e == 2 ? av[mr][q].z : av[mr][q].w;
-#pragma unroll
-                            for (int nr = 0; nr < NR; ++nr)
-                                if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nr], acc[mr][nr], 0, 0, 0);
-                        }
-                    }
+                    for (int nr = 0; nr < NR; ++nr)
+                        if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nr], acc[mr][nr], 0, 0, 0);
                 }
             }
         }
-        if (cs + 1 < NCS) {
-            stage_store(buf ^ 1);  // nobody reads that buffer any more: its last readers passed the barrier that ended step cs - 1
-            __syncthreads();
+    };
+    float4 avA[MR][4], avB[MR][4];
+    stage_load(0);
+    if (mine) load_a(0, 0, avA);
+    stage_store(0);
+    __syncthreads();
+    // steps in pairs (cs0, cs0 + 1) so that LDS buffer and register-set parities are compile-time positions (K is odd: the parity of the first tap flips from
+    // one step to the next)
+#pragma unroll 1
+    for (int cs0 = 0; cs0 < NCS; cs0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cs = cs0 + u;
+            if (cs >= NCS) break;  // uniform
+            if (cs + 1 < NCS) stage_load(cs + 1);  // in flight under this step's MFMAs
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bool last = j + 1 == K;
+                    const int ncs = last ? cs + 1 : cs, nj = last ? 0 : j + 1;
+                    const bool more = ncs < NCS;
+                    if (((u * K + j) & 1) == 0) {
+                        if (more) load_a(ncs, nj, avB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(u, j, avA);
+                    } else {
+                        if (more) load_a(ncs, nj, avA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(u, j, avB);
+                    }
+                }
+            }
+            if (cs + 1 < NCS) {
+                stage_store(u ^ 1);  // nobody reads that buffer any more: its last readers passed the barrier that ended step cs - 1
+                __syncthreads();
+            }
         }
     }
     if (!mine) return;
