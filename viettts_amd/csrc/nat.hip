@@ -512,20 +512,29 @@ __global__ void nat_duration_head_k(const float* __restrict__ enc, const int* __
 }
 
 // AcousticModel.upsample (model.py:102-111): cond[b][f][:] = sum_j softmax_j(-(mid_j - f)^2 / 10) * enc[b][j][:], with
-// mid = cumsum(d) - d/2, d in frames.  One block per (frame, sentence); blockDim = 256; E = 2D encoder channels.
-__global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ enc, const int* __restrict__ lengths, const float* __restrict__ dur,
-                                                      const int* __restrict__ nframes, float* __restrict__ cond, int Lmax, int Fmax, int E) {
-    extern __shared__ float sw[];  // mid[Lmax] then weights[Lmax], + 8 for reductions
-    float* mid = sw;
-    float* wgt = sw + Lmax;
-    float* red = sw + 2 * Lmax;
-    const int b = blockIdx.y, f = blockIdx.x, j = threadIdx.x;
-    const int len = lengths[b];
-    if (f >= nframes[b]) {
-        for (int c = j; c < E; c += blockDim.x) cond[((size_t)b * Fmax + f) * E + c] = 0.0f;
-        return;
-    }
-    if (j == 0) {  // jnp.cumsum: sequential fp32 prefix sum
+// mid = cumsum(d) - d/2, d in frames; E = 2D encoder channels.
+// The conditioning's share of the LSTM gates WITHOUT materialising the conditioning (round 4).  cond[b][f] = sum_k a[b][f][k] enc[b][k]
+// only ever meets the first E rows of the two LSTMs' input matrices (x = [cond_f ; p], model.py:134-141), so
+//   G_l[b][f] = b_l + cond[b][f] @ W_l[0:E] = b_l + sum_k a[b][f][k] (enc[b][k] @ W_l[0:E]):
+// the GEMM runs over TOKENS (EG_l = enc @ W_l[0:E], nat_conv_mfma_k with one tap; a sixth of the frames' rows: 302 -> 37 GFLOP for 256 sentences)
+// and this kernel mixes its rows into the frames' rows with the upsampling weights a = softmax_k(-(mid_k - f)^2 / 10), mid = cumsum(d) - d/2.
+// A workgroup = NAT_MIX_FT frames x 1024 gate columns of one sentence and one layer: the weights of its frames in LDS ([token][frame]: four
+// 16-byte broadcast reads per token), a thread's 4 columns x NAT_MIX_FT frames in registers, EG rows streamed from L2 (coalesced float4).
+// Sums in token order, weights from the sentence's own durations: a row does not depend on its batch.
+constexpr int NAT_MIX_FT = 16;
+__global__ __launch_bounds__(256) void nat_gates_mix_k(const float* __restrict__ eg1, const float* __restrict__ eg2, const float* __restrict__ bias1,
+                                                       const float* __restrict__ bias2, const int* __restrict__ lengths, const float* __restrict__ dur,
+                                                       const int* __restrict__ nframes, float* __restrict__ G1, float* __restrict__ G2, int Lmax, int Fmax,
+                                                       int G4, int tile0) {
+    constexpr int FT = NAT_MIX_FT;
+    extern __shared__ float sw[];
+    float* mid = sw;                       // [Lmax rounded up to 4]
+    float* wn = sw + (Lmax + 3) / 4 * 4;   // [Lmax][FT]
+    const int b = blockIdx.z, f0 = (blockIdx.x + tile0) * FT, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int len = lengths[b], nf = nframes[b];
+    if (f0 >= nf) return;  // rows at or past the sentence's frames are never used (the step kernel masks them)
+    const int chunks = G4 / 1024, layer = blockIdx.y / chunks, col = (blockIdx.y % chunks) * 1024 + 4 * t;
+    if (t == 0) {  // jnp.cumsum: sequential fp32 prefix sum
         float end = 0.0f;
         for (int k = 0; k < len; ++k) {
             const float d = dur[(size_t)b * Lmax + k];
@@ -534,33 +543,54 @@ __global__ __launch_bounds__(256) void nat_upsample_k(const float* __restrict__ 
         }
     }
     __syncthreads();
-    float mx = -INFINITY;
-    for (int k = j; k < len; k += blockDim.x) {
-        const float z = mid[k] - (float)f;
-        const float v = -(z * z) / 10.0f;
-        wgt[k] = v;
-        mx = fmaxf(mx, v);
+    // a wave takes FT / 4 of the tile's frames, one after the other: max and sum over the tokens in a fixed butterfly order
+    for (int q = 0; q < FT / 4; ++q) {
+        const int fi = wave * (FT / 4) + q;
+        const float ff = (float)(f0 + fi);
+        float mx = -INFINITY;
+        for (int k = lane; k < len; k += 64) {
+            const float z = mid[k] - ff;
+            mx = fmaxf(mx, -(z * z) / 10.0f);
+        }
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.0f;
+        for (int k = lane; k < len; k += 64) {
+            const float z = mid[k] - ff;
+            const float e = expf(-(z * z) / 10.0f - mx);
+            wn[k * FT + fi] = e;
+            sum += e;
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        for (int k = lane; k < len; k += 64) wn[k * FT + fi] = wn[k * FT + fi] / sum;
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_down(mx, o, 64));
-    if ((j & 63) == 0) red[j >> 6] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float sum = 0.0f;
-    for (int k = j; k < len; k += blockDim.x) {
-        const float e = expf(wgt[k] - mx);
-        wgt[k] = e;
-        sum += e;
+    const float* __restrict__ eg = (layer ? eg2 : eg1) + (size_t)b * Lmax * G4 + col;
+    const float4 bv = *reinterpret_cast<const float4*>((layer ? bias2 : bias1) + col);
+    float4 acc[FT];
+#pragma unroll
+    for (int i = 0; i < FT; ++i) acc[i] = bv;
+#pragma unroll 4
+    for (int k = 0; k < len; ++k) {
+        const float4 e = *reinterpret_cast<const float4*>(eg + (size_t)k * G4);
+        const float4* __restrict__ w4 = reinterpret_cast<const float4*>(wn + k * FT);
+#pragma unroll
+        for (int q = 0; q < FT / 4; ++q) {
+            const float4 w = w4[q];
+            const float ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float4& a = acc[4 * q + i];
+                a.x = fmaf(ws[i], e.x, a.x);
+                a.y = fmaf(ws[i], e.y, a.y);
+                a.z = fmaf(ws[i], e.z, a.z);
+                a.w = fmaf(ws[i], e.w, a.w);
+            }
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
-    __syncthreads();  // everyone has read red[] (the max) before it is reused
-    if ((j & 63) == 0) red[4 + (j >> 6)] = sum;
-    __syncthreads();
-    sum = (red[4] + red[5]) + (red[6] + red[7]);
-    for (int c = j; c < E; c += blockDim.x) {
-        float acc = 0.0f;
-        for (int k = 0; k < len; ++k) acc = fmaf(wgt[k] / sum, enc[((size_t)b * Lmax + k) * E + c], acc);
-        cond[((size_t)b * Fmax + f) * E + c] = acc;
-    }
+    float* __restrict__ G = (layer ? G2 : G1) + ((size_t)b * Fmax + f0) * G4 + col;
+#pragma unroll
+    for (int i = 0; i < FT; ++i)
+        if (f0 + i < nf) *reinterpret_cast<float4*>(G + (size_t)i * G4) = acc[i];
 }
 
 // AcousticModel.inference's scan body (model.py:134-141) for ALL sentences of the batch at once, one launch per layer per
@@ -610,12 +640,17 @@ struct NatLstmOps {
                          // a lane's 16 accumulators are 64 contiguous bytes.  nullptr = start from the bias.
     size_t gpitch;
 };
-template <int NT, int KW>
+template <int NT, int KW, int SL = 1>
 __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLstmOps ops1, int KA, int KB, const int* __restrict__ nframes, int f, int B,
                                                           int Bp, int H) {
+    // SL = slices (8 units each) per workgroup: a wave's state fragments feed SL weight fragments, so the state's share of the L2 -> CU stream
+    // (2/3 of it at SL = 1, NT = 2: every slice's workgroup reads the whole state of its sentences) falls by SL.  Each output element's sum is
+    // the same chain in the same order whatever SL is.  MEASURED (round 4, 256 sentences): SL = 2 makes the step 19.3 -> 28.9 us — the step is not
+    // bound by that stream but by what ONE workgroup has to do (its fp32 MFMAs: 2 waves per SIMD x K/64 iterations x 8 x 64 cycles = 6-10 us, and
+    // a cold L2 at every launch: 17.5 MB of misses per step, PMC passes in profiles/r04_e_nat_decoder_findings.md); the launches use SL = 1.
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     static_assert(KW == 1 || KW == 2 || KW == 4 || KW == 8, "tree reduction");
-    __shared__ float red[KW > 1 ? KW / 2 : 1][NT][16][64];
+    __shared__ float red[KW > 1 ? KW / 2 : 1][SL][NT][16][64];
     const NatLstmOps& ops = blockIdx.z ? ops1 : ops0;
     const float* __restrict__ inA = ops.inA;
     const float* __restrict__ inB = ops.inB;
@@ -624,7 +659,7 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     float* __restrict__ cst = ops.cst;
     float* __restrict__ hout = ops.hout;
     const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
-    const int slice = blockIdx.x, b0 = blockIdx.y * 32 * NT;
+    const int slice0 = blockIdx.x * SL, b0 = blockIdx.y * 32 * NT;
     bool live[NT];
     bool any = false;
 #pragma unroll
@@ -636,43 +671,49 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     if (__ballot(any) == 0ull) return;  // every sentence of these tiles has all its frames (same for all waves)
     const int NIT = (KA + KB) / 8, NWMAX = (NIT + KW - 1) / KW, it_lo = kw * NWMAX;
     const int NW = it_lo >= NIT ? 0 : (NIT - it_lo < NWMAX ? NIT - it_lo : NWMAX);  // this wave's iterations [it_lo, it_lo + NW)
-    f32x16 acc[NT][2];
+    f32x16 acc[SL][NT][2];
     if (ops.gin != nullptr && kw == 0) {
         // the sum starts from the hoisted part (bias + the inputs known ahead of the loop, themselves an MFMA chain in k order)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int b = b0 + 32 * nt + l31;
-            const float4* __restrict__ gp = reinterpret_cast<const float4*>(ops.gin + (size_t)(b < B ? b : B - 1) * ops.gpitch + (size_t)(2 * slice + lh) * 16);
+        for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 g4 = gp[rq];
-                acc[nt][0][4 * rq + 0] = g4.x;
-                acc[nt][0][4 * rq + 1] = g4.y;
-                acc[nt][0][4 * rq + 2] = g4.z;
-                acc[nt][0][4 * rq + 3] = g4.w;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int b = b0 + 32 * nt + l31;
+                const float4* __restrict__ gp =
+                    reinterpret_cast<const float4*>(ops.gin + (size_t)(b < B ? b : B - 1) * ops.gpitch + (size_t)(2 * (slice0 + sl) + lh) * 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[nt][1][4 * rq + i] = 0.0f;
-            }
-        }
-    } else {
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 g4 = gp[rq];
+                    acc[sl][nt][0][4 * rq + 0] = g4.x;
+                    acc[sl][nt][0][4 * rq + 1] = g4.y;
+                    acc[sl][nt][0][4 * rq + 2] = g4.z;
+                    acc[sl][nt][0][4 * rq + 3] = g4.w;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float bv = (kw == 0 && ops.gin == nullptr) ? bias[i * H + 8 * slice + 2 * rq + lh] : 0.0f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    acc[nt][0][4 * rq + i] = bv;
-                    acc[nt][1][4 * rq + i] = 0.0f;
+                    for (int i = 0; i < 4; ++i) acc[sl][nt][1][4 * rq + i] = 0.0f;
                 }
             }
+    } else {
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bv = (kw == 0 && ops.gin == nullptr) ? bias[i * H + 8 * (slice0 + sl) + 2 * rq + lh] : 0.0f;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[sl][nt][0][4 * rq + i] = bv;
+                        acc[sl][nt][1][4 * rq + i] = 0.0f;
+                    }
+                }
     }
-    float4 wv[NAT_DEC_PD];
+    float4 wv[NAT_DEC_PD][SL];
     float4 xv[NAT_DEC_PD][NT];
-    const float4* __restrict__ wsl = wpk + (size_t)slice * NIT * 64 + lane;
+    const float4* __restrict__ wsl = wpk + (size_t)slice0 * NIT * 64 + lane;
     auto load_it = [&](int it, int slot) {
         if (it >= NIT) it = NIT - 1;  // tail: an in-bounds re-read, never used
-        wv[slot] = wsl[(size_t)it * 64];
+#pragma unroll
+        for (int sl = 0; sl < SL; ++sl) wv[slot][sl] = wsl[((size_t)sl * NIT + it) * 64];
         const int k0 = it * 8;
         // rows k0 + 4*lh .. + 3 of this lane's sentences: MFMA j of the iteration takes k = k0 + 4*(lane/32) + j on both operands
         const float* __restrict__ xr = (k0 < KA ? inA + (size_t)k0 * Bp : inB + (size_t)(k0 - KA) * Bp) + ((size_t)lh * Bp + b0 + l31) * 4;
@@ -687,46 +728,60 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
         for (int j = 0; j < NAT_DEC_PD; ++j) {
             if (it0 + j >= NW) break;  // wave-uniform
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].x, xv[j][nt].x, acc[nt][0], 0, 0, 0);
+            for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].y, xv[j][nt].y, acc[nt][1], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[sl][nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][sl].x, xv[j][nt].x, acc[sl][nt][0], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].z, xv[j][nt].z, acc[nt][0], 0, 0, 0);
+            for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j].w, xv[j][nt].w, acc[nt][1], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) acc[sl][nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][sl].y, xv[j][nt].y, acc[sl][nt][1], 0, 0, 0);
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[sl][nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][sl].z, xv[j][nt].z, acc[sl][nt][0], 0, 0, 0);
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[sl][nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][sl].w, xv[j][nt].w, acc[sl][nt][1], 0, 0, 0);
             const int nx = it0 + j + NAT_DEC_PD;
             load_it(nx < NW ? it_lo + nx : NIT, j);
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][0][r] += acc[nt][1][r];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[sl][nt][0][r] += acc[sl][nt][1][r];
     // fixed-order tree over the K shares: waves [half, 2*half) hand their sums to waves [0, half)
 #pragma unroll
     for (int half = KW / 2; half >= 1; half >>= 1) {
         if (kw >= half && kw < 2 * half) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[kw - half][nt][r][lane] = acc[nt][0][r];
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[kw - half][sl][nt][r][lane] = acc[sl][nt][0][r];
         }
         __syncthreads();
         if (kw < half) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][0][r] += red[kw][nt][r][lane];
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[sl][nt][0][r] += red[kw][sl][nt][r][lane];
         }
         if (half > 1) __syncthreads();
     }
     // The cell update (3 sigmoids + 2 tanh per (unit, sentence): ~1000 VALU instructions per lane for a wave's 8 pairs) is shared out: wave 0
-    // hands the gate sums to the workgroup through LDS and wave w takes the (sentence tile, unit pair) blocks w, w + KW, ...  Round 2 left it to
-    // wave 0 alone while the other seven idled: ~2.5 us of every 22 us step.  The same operations on the same values: the same bits.
-    auto cell_update = [&](int nt, int rq, float gi, float gg, float gf, float go) {
+    // hands the gate sums to the workgroup through LDS and wave w takes the (slice, sentence tile, unit pair) blocks w, w + KW, ...  Round 2 left
+    // it to wave 0 alone while the other seven idled: ~2.5 us of every 22 us step.  The same operations on the same values: the same bits.
+    auto cell_update = [&](int sl, int nt, int rq, float gi, float gg, float gf, float go) {
         if (!live[nt]) return;
         const int b = b0 + 32 * nt + l31;
-        const int u = 8 * slice + 2 * rq + lh;
+        const int u = 8 * (slice0 + sl) + 2 * rq + lh;
         float c = cst[(size_t)u * Bp + b];
         c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
         cst[(size_t)u * Bp + b] = c;
@@ -734,22 +789,28 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     };
     if constexpr (KW == 1) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) cell_update(nt, rq, acc[nt][0][4 * rq + 0], acc[nt][0][4 * rq + 1], acc[nt][0][4 * rq + 2], acc[nt][0][4 * rq + 3]);
-    } else {
-        if (kw == 0) {  // (it was the only reader of red[0] at the tree's last level, and nothing else writes it now)
+        for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[0][nt][r][lane] = acc[nt][0][r];
+                for (int rq = 0; rq < 4; ++rq)
+                    cell_update(sl, nt, rq, acc[sl][nt][0][4 * rq + 0], acc[sl][nt][0][4 * rq + 1], acc[sl][nt][0][4 * rq + 2], acc[sl][nt][0][4 * rq + 3]);
+    } else {
+        if (kw == 0) {  // (it was the only reader of red[0] at the tree's last level, and nothing else writes it now)
+#pragma unroll
+            for (int sl = 0; sl < SL; ++sl)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[0][sl][nt][r][lane] = acc[sl][nt][0][r];
         }
         __syncthreads();
 #pragma unroll
-        for (int blk = 0; blk < NT * 4; ++blk) {
+        for (int blk = 0; blk < SL * NT * 4; ++blk) {
             if (blk % KW != kw) continue;  // wave-uniform
-            const int nt = blk / 4, rq = blk % 4;
-            cell_update(nt, rq, red[0][nt][4 * rq + 0][lane], red[0][nt][4 * rq + 1][lane], red[0][nt][4 * rq + 2][lane], red[0][nt][4 * rq + 3][lane]);
+            const int sl = blk / (NT * 4), nt = (blk / 4) % NT, rq = blk % 4;
+            cell_update(sl, nt, rq, red[0][sl][nt][4 * rq + 0][lane], red[0][sl][nt][4 * rq + 1][lane], red[0][sl][nt][4 * rq + 2][lane],
+                        red[0][sl][nt][4 * rq + 3][lane]);
         }
     }
 }
@@ -1212,6 +1273,9 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
             const std::vector<float>& bv = m.arrs[m.find(mod, "b")].host;
             for (int cp = 0; cp < G4; ++cp) out[cp] = bv[hcol(cp)];
         });
+        h->add_extra(mod + "#zerob", (size_t)G4 * sizeof(float), [G4](const NatModel&, float* out) {  // the token-rows GEMM adds no bias (the mix does)
+            for (int cp = 0; cp < G4; ++cp) out[cp] = 0.0f;
+        });
     }
     h->layout();
     *out = h;
@@ -1253,7 +1317,7 @@ VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B
     if (B <= 0 || Lmax <= 0 || Fmax <= 0) return failf(VTTS_ERR_INVALID, "B, Lmax and Fmax must be positive (got %d, %d, %d)", B, Lmax, Fmax);
     const size_t D = h->cfg.encoder_dim, PD = h->cfg.postnet_dim, MEL = h->cfg.mel_dim;
     *bytes = 2 * align_up((size_t)B * Lmax * D * 4, 256) + align_up((size_t)B * Lmax * 2 * D * 4, 256)  // encoder ping-pong + output
-             + align_up((size_t)B * Fmax * 2 * D * 4, 256)                                                 // cond
+             + 2 * align_up((size_t)B * Lmax * 4 * h->cfg.decoder_dim * 4, 256)                           // EG1, EG2: enc @ W_l[0:E] per token
              + align_up((size_t)B * Fmax * MEL * 4, 256)                                                   // decoder mel
              + 2 * align_up((size_t)B * Fmax * PD * 4, 256)                                                // postnet ping-pong
              + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256)                                          // decoder state Z[2], c1, c2
@@ -1336,7 +1400,8 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
     float* bufA = take((size_t)B * Lmax * D * 4);
     float* bufB = take((size_t)B * Lmax * D * 4);
     float* enc = take((size_t)B * Lmax * E * 4);
-    float* cond = take((size_t)B * Fmax * E * 4);
+    float* EG1 = take((size_t)B * Lmax * G4 * 4);
+    float* EG2 = take((size_t)B * Lmax * G4 * 4);
     float* mel0 = take((size_t)B * Fmax * MEL * 4);
     float* pA = take((size_t)B * Fmax * PD * 4);
     float* pB = take((size_t)B * Fmax * PD * 4);
@@ -1346,8 +1411,7 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
     float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);
     rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);  // model.py:131
     if (rc) return rc;
-    hipLaunchKernelGGL(nat_upsample_k, dim3(Fmax, B), dim3(256), (2 * Lmax + 8) * sizeof(float), s, enc, lengths_dev, durations_dev, nframes_dev, cond,
-                       Lmax, Fmax, E);  // :132
+    // :132 (upsample) lives inside the gates below: cond is never materialised (nat_gates_mix_k)
     HIP_TRYN(hipMemsetAsync(mel_dev, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame
     // postnet (:113-121) + residual (:151) of rows [r0, r1) over their first `frames` frames: 4 x (Conv1D(PD, 5) + BatchNorm + tanh),
     // Conv1D(MEL, 5), mel + .   A row's result does not depend on the launch it is part of.
@@ -1379,21 +1443,29 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
         float* c2 = c1 + (size_t)H * Bp;
         HIP_TRYN(hipMemsetAsync(dstate, 0, nat_dec_state_floats(h->cfg, B) * 4, s));  // frame 0: h1 = h2 = 0, c = 0, prenet(0) = 0 (no biases)
         HIP_TRYN(hipMemsetAsync(mel0, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame stay zero
-        // the conditioning's share of both layers' gates for every frame: tiles [0, 1) of 64 frames here, the rest beside the first 64 steps
-        const int tiles = (Fmax + 63) / 64, MBG = G4 / 32;
+        // the conditioning's share of both layers' gates for every frame (nat_gates_mix_k): the GEMM over the tokens' rows, then the mix for
+        // frames [0, 64) here and for the rest beside the first 64 steps
+        const int MBG = G4 / 32;
+        if (G4 % 1024 != 0) return failf(VTTS_ERR_INVALID, "decoder_dim %d: the gate mix wants 4 * decoder_dim in multiples of 1024", H);
+        hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
+                           reinterpret_cast<const float4*>(h->extra("lstm/linear#cond")), h->extra("lstm/linear#zerob"), nullptr, nullptr, nullptr, nullptr, EG1, Lmax,
+                           E, G4, (int)NAT_ACT_NONE, 0);
+        hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
+                           reinterpret_cast<const float4*>(h->extra("lstm_1/linear#cond")), h->extra("lstm_1/linear#zerob"), nullptr, nullptr, nullptr, nullptr, EG2,
+                           Lmax, E, G4, (int)NAT_ACT_NONE, 0);
+        const size_t mlds = ((size_t)(Lmax + 3) / 4 * 4 + (size_t)Lmax * NAT_MIX_FT) * sizeof(float);
+        if (mlds > 48 * 1024)
+            HIP_TRYN(hipFuncSetAttribute(reinterpret_cast<const void*>(&nat_gates_mix_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+        const int mtiles = (Fmax + NAT_MIX_FT - 1) / NAT_MIX_FT, mfirst = 64 / NAT_MIX_FT < mtiles ? 64 / NAT_MIX_FT : mtiles;
         auto gates = [&](int tile0, int ntiles, hipStream_t gs) {
-            hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3(ntiles, (MBG + 7) / 8, B), dim3(256), 0, gs, cond, nframes_dev,
-                               reinterpret_cast<const float4*>(h->extra("lstm/linear#cond")), h->extra("lstm/linear#condb"), nullptr, nullptr, nullptr, nullptr, G1,
-                               Fmax, E, G4, (int)NAT_ACT_NONE, tile0);
-            hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3(ntiles, (MBG + 7) / 8, B), dim3(256), 0, gs, cond, nframes_dev,
-                               reinterpret_cast<const float4*>(h->extra("lstm_1/linear#cond")), h->extra("lstm_1/linear#condb"), nullptr, nullptr, nullptr, nullptr, G2,
-                               Fmax, E, G4, (int)NAT_ACT_NONE, tile0);
+            hipLaunchKernelGGL(nat_gates_mix_k, dim3(ntiles, 2 * (G4 / 1024), B), dim3(256), mlds, gs, EG1, EG2, h->extra("lstm/linear#condb"),
+                               h->extra("lstm_1/linear#condb"), lengths_dev, durations_dev, nframes_dev, G1, G2, Lmax, Fmax, G4, tile0);
         };
-        gates(0, 1, s);
-        if (tiles > 1) {
+        gates(0, mfirst, s);
+        if (mtiles > mfirst) {
             HIP_TRYN(hipEventRecord(h->ev_fork, s));
             HIP_TRYN(hipStreamWaitEvent(h->side, h->ev_fork, 0));
-            gates(1, tiles - 1, h->side);
+            gates(mfirst, mtiles - mfirst, h->side);
             HIP_TRYN(hipEventRecord(h->ev_gates, h->side));
         }
         const float4* w1 = reinterpret_cast<const float4*>(h->extra("lstm/linear#mfma"));
