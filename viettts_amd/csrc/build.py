@@ -30,6 +30,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
 #    computed wrong mel frames for its even sentences (tools/experiments/r04/diag_pipe3.py; isolated in tools/kbench/pkfma_hazard.hip;
 #    profiles/r04_a_pkfma_findings.md).  Kernels that never run beside the bf16 engine would be safe with them, but a caller may put any
 #    two handles on two streams, so none keeps them (the fp32 convolutions lose ~1 %).
+# (The LOOP vectoriser can form them too, from a lane-strided scalar loop: such loops carry `#pragma clang loop vectorize(disable)` —
+# nat.hip: nat_gates_mix_k — and tests/test_cabi.py disassembles the built library, which is what holds the rule.)
 FILE_FLAGS = {name: ["-fno-slp-vectorize"] for name in SOURCES}
 LIBNAME = "libvtts_hifigan.so"
 

@@ -548,12 +548,14 @@ __global__ __launch_bounds__(256) void nat_gates_mix_k(const float* __restrict__
         const int fi = wave * (FT / 4) + q;
         const float ff = (float)(f0 + fi);
         float mx = -INFINITY;
+#pragma clang loop vectorize(disable)  // the loop vectoriser would pair these into v_pk_*_f32 (build.py: no packed-f32 VALU code)
         for (int k = lane; k < len; k += 64) {
             const float z = mid[k] - ff;
             mx = fmaxf(mx, -(z * z) / 10.0f);
         }
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         float sum = 0.0f;
+#pragma clang loop vectorize(disable)  // the loop vectoriser would pair these into v_pk_*_f32 (build.py: no packed-f32 VALU code)
         for (int k = lane; k < len; k += 64) {
             const float z = mid[k] - ff;
             const float e = expf(-(z * z) / 10.0f - mx);
@@ -561,6 +563,7 @@ __global__ __launch_bounds__(256) void nat_gates_mix_k(const float* __restrict__
             sum += e;
         }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma clang loop vectorize(disable)
         for (int k = lane; k < len; k += 64) wn[k * FT + fi] = wn[k * FT + fi] / sum;
     }
     __syncthreads();
