@@ -226,7 +226,7 @@ def pmc_counters(kernel: str, args, B: int, T: int):
     return traffic, util, None
 
 
-def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=1, passes=3):
+def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=1, passes=3, nat_bf16x3=False):
     """BASELINE.json configs[3]: n sentences cycled from the reference's demo transcript x the InfoRe lexicon (SURVEY.md §8d;
     fixtures tests/golden/text/, token ids pinned to the reference's own text2tokens) with synthetic checkpoints -> NAT
     duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) -> HiFi-GAN bf16 in
@@ -253,6 +253,8 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=
     # rank 0 loads and packs each checkpoint, the other ranks receive the packed blobs: one broadcast per model
     dm = vdist.setup_model_dp(DurationModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_duration_checkpoint()))
     am = vdist.setup_model_dp(AcousticModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_acoustic_checkpoint()))
+    if nat_bf16x3:  # the acoustic model's split-precision option (include/vtts_nat.h): for a bf16-class vocoder the mel's 1e-5 is noise
+        am.set_option("bf16x3", 1)
     tdir = os.path.join(REPO, "tests", "golden", "text")
     sents = transcript_sentences(n, os.path.join(tdir, "transcript.txt"), os.path.join(tdir, "lexicon.txt"))
     out = {}
@@ -277,6 +279,7 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=
                # only the host's enqueue time of the acoustic model is separable; generator_ms then covers everything from there to the last sample
                # (0.0 = not applicable to the schedule this rank ran)
                "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3, "acoustic_enqueue_ms": tm.get("acoustic_enqueue_s", 0.0) * 1e3,
+               "acoustic_precision": "bf16x3 option" if nat_bf16x3 else "fp32",
                "overlap_groups": tm.get("overlap_groups", 1), "pinned_alloc_ms": tm.get("pinned_alloc_s", 0.0) * 1e3,
                "generator_ms": tm.get("generator_s", 0.0) * 1e3, "total_ms": total * 1e3}
     dm.close()

@@ -408,6 +408,42 @@ def test_acoustic_wide_batch_rows_equal_rows_alone(acoustic):
     assert np.abs(got[40] - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
 
 
+def test_acoustic_bf16x3_option(acoustic, capsys):
+    """Option "bf16x3" (include/vtts_nat.h): the postnet's products as three bf16 x bf16 terms on the bf16 matrix pipe.  The mel stays within
+    2e-4 of its range of the fp32 mode's (observed ~1e-5) and within the fp32 mode's own bound of the fp64 oracle; rows stay independent of
+    their batch; the option reads back, and an unknown key is refused."""
+    m, P, S = acoustic
+    cases = [_case(31, 9), _case(32, 30), _case(33, 1), _case(34, 17)]
+    seeds = [61, 62, 63, 64]
+    args = ([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases])
+    ref = m(*args, dropout_seeds=seeds)
+    assert m.get_option("bf16x3") == 0
+    m.set_option("bf16x3", 1)
+    try:
+        assert m.get_option("bf16x3") == 1
+        got = m(*args, dropout_seeds=seeds)
+        alone = m([cases[1][0]], [cases[1][1]], [cases[1][2]], dropout_seeds=[seeds[1]])[0]
+    finally:
+        m.set_option("bf16x3", 0)
+    assert np.array_equal(alone, got[1])
+    worst = 0.0
+    for (tok, dur, nf), g, r, sd in zip(cases, got, ref, seeds):
+        scale = max(1.0, float(np.abs(r).max()))
+        worst = max(worst, float(np.abs(g - r).max()) / scale)
+        masks = no.threefry_keep_masks(sd, nf, 256)
+        orc = no.acoustic_inference(P, S, np.array(tok), dur, nf, prenet_masks=lambda f: (masks[f, 0], masks[f, 1]))
+        assert np.abs(g - orc).max() < 5e-4 * max(1.0, np.abs(orc).max())
+    with capsys.disabled():
+        print(f"[acoustic model, bf16x3 option vs fp32 mode] max|d mel| / range {worst:.2e}")
+    assert 0.0 < worst < 2e-4
+    from viettts_amd._lib import VttsError
+
+    with pytest.raises(VttsError):
+        m.set_option("no_such_option", 1)
+    with pytest.raises(VttsError):
+        m.set_option("bf16x3", 2)
+
+
 def test_nat_models_run_from_an_adopted_blob(model, acoustic):
     """The data-parallel start-up (viettts_amd.dist.setup_model_dp): a rank that never saw the checkpoint binds the
     packed blob rank 0 broadcast and computes the same durations and mel bit for bit."""

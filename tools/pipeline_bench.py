@@ -10,6 +10,7 @@ from bench import pipeline_256  # noqa: E402
 
 if __name__ == "__main__":
     og = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # overlap groups: 1 = stages one after the other (the default), G > 1 = the opt-in overlapped schedule
-    r = pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256, overlap_groups=og, passes=int(sys.argv[3]) if len(sys.argv) > 3 else 2)
+    r = pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256, overlap_groups=og, passes=int(sys.argv[3]) if len(sys.argv) > 3 else 2,
+                     nat_bf16x3=len(sys.argv) > 4 and sys.argv[4] == "x3")
     r["samples_per_s"] = r["samples"] / (r["total_ms"] * 1e-3)
     print(json.dumps(r))

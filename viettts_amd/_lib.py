@@ -76,6 +76,8 @@ NAT_EXPORTS = (
     "vtts_nat_acoustic_pack",
     "vtts_nat_acoustic_bind_packed",
     "vtts_nat_acoustic_workspace_bytes",
+    "vtts_nat_acoustic_set_option",
+    "vtts_nat_acoustic_get_option",
     "vtts_nat_acoustic_keep_masks",
     "vtts_nat_acoustic_keep_masks_haiku",
     "vtts_nat_acoustic_keep_masks_haiku_mode",
@@ -209,6 +211,8 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_acoustic_pack": (C.c_int, [vp, vp, sz, vp]),
         "vtts_nat_acoustic_bind_packed": (C.c_int, [vp, vp, sz]),
         "vtts_nat_acoustic_workspace_bytes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(sz)]),
+        "vtts_nat_acoustic_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "vtts_nat_acoustic_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int)]),
         "vtts_nat_acoustic_keep_masks": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_keep_masks_haiku": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, vp, vp]),
         "vtts_nat_acoustic_keep_masks_haiku_mode": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, vp, vp]),

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/vtts_hifigan.h"
+#include "bf16_common.h"
 #include "vtts_internal.h"
 
 #define VTTS_API extern "C" __attribute__((visibility("default")))
@@ -230,8 +231,23 @@ struct NatModel {
 struct vtts_nat_duration : NatModel {
     vtts_nat_duration_cfg cfg;
 };
+// round-to-nearest-even bf16 of a float (host side of the bf16x3 split: v0 = bf16(v), v1 = bf16(v - v0); v - v0 is exact in fp32)
+static inline unsigned short nat_bf16_rne(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float nat_bf16_to_float(unsigned short h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
 struct vtts_nat_acoustic : NatModel {
     vtts_nat_acoustic_cfg cfg;
+    int x3 = 0;  // option "bf16x3": the postnet's convolutions as three bf16 x bf16 terms on the bf16 matrix pipe (nat_conv_x3_k)
     // forward_groups(): the postnet of a group of rows runs on `side` as soon as the decoder has produced the group's last frame
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gates = nullptr;
@@ -450,6 +466,186 @@ __global__ __launch_bounds__(256, 2) void nat_conv_mfma_k(const float* __restric
         for (int rq = 0; rq < 4; ++rq) {
             const int co = 32 * (mb0 + mr) + 8 * rq + 4 * lh;
             if (mb0 + mr >= MB || co >= Cout) continue;  // Cout is a multiple of 4: a lane's 4 channels are in or out together
+            float iv[4] = {1.f, 1.f, 1.f, 1.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bn) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    iv[i] = inv[co + i];
+                    mv[i] = mean[co + i];
+                    ov[i] = offset[co + i];
+                }
+            }
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = t0 + nr * 32 + l31;
+                if (t >= Lmax || (nr == 1 && !two)) continue;
+                const size_t o = ((size_t)b * Lmax + t) * Cout + co;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[mr][nr][4 * rq + i];
+                    if (bn) v[i] = (v[i] - mv[i]) * iv[i] + ov[i];
+                    if (act == NAT_ACT_RELU) v[i] = fmaxf(v[i], 0.0f);
+                    else if (act == NAT_ACT_TANH) v[i] = tanhf(v[i]);
+                }
+                if (res) {
+                    const float4 r = *reinterpret_cast<const float4*>(res + o);
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                if (t >= len) v[0] = v[1] = v[2] = v[3] = 0.0f;
+                *reinterpret_cast<float4*>(y + o) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+
+// The same convolution with every product as three bf16 x bf16 terms on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32 accumulation):
+// v = v0 + v1 with v0 = bf16(v), v1 = bf16(v - v0) (16 mantissa bits), x * w ~ x1 w0 + x0 w1 + x0 w0 (the dropped x1 w1 is 2^-18 of the
+// product) — the split of the vocoder's bf16x3 engine (kernels_x3.hip; profiles/r04_b_split_findings.md).  An OPTION of the acoustic model
+// (vtts_nat_acoustic_set_option "bf16x3"), not its default: the fp32 kernel above is what the parity tests against the reference pin at 5e-5;
+// this one is for callers whose vocoder is bf16-class anyway (the text -> waveform pipeline).  Same tile, same epilogue; per 32-channel step
+// and tap 6 matrix instructions of 32 cycles instead of 16 of 64.  Weights pre-split at pack time ("…#x3": [mblk][step][tap][16-channel
+// half][hi | lo][lane][8] bf16, as many bytes as the fp32 fragments); the activations are split while they are staged: two bf16 LDS planes,
+// rows of 32 channels padded to 80 bytes (eight lanes' 16-byte reads cover the 32 banks).
+template <int K, int MR>
+__global__ __launch_bounds__(256, 2) void nat_conv_x3_k(const float* __restrict__ x, const int* __restrict__ lengths, const uint4* __restrict__ wpk,
+                                                     const float* __restrict__ bias, const float* __restrict__ inv, const float* __restrict__ mean,
+                                                     const float* __restrict__ offset, const float* __restrict__ res, float* __restrict__ y, int Lmax,
+                                                     int Cin, int Cout, int act, int tile0) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    using vtts::bf16x8;
+    constexpr int NR = 2, PL = (K - 1) / 2, ROWS = 64 + K - 1, RSB = 40, UNITS = ROWS * 8, UPT = (UNITS + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short xs[2][2][ROWS * RSB];  // [buffer][hi | lo][row][32 channels + 8 pad] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, t0 = (blockIdx.x + tile0) * 64;
+    const int len = lengths[b];
+    const int MB = (Cout + 31) / 32, NCS = (Cin + 31) / 32;
+    const int mb0 = (blockIdx.y * 4 + wave) * MR;
+    if (t0 >= len) return;
+    const bool mine = mb0 < MB;
+    const bool two = len - t0 > 32;
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = 32 * (mb0 + mr) + 8 * rq + 4 * lh + i;
+                const float bv = (mb0 + mr < MB && co < Cout) ? bias[co] : 0.0f;
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr) acc[mr][nr][4 * rq + i] = bv;
+            }
+    const float* __restrict__ xb = x + (size_t)b * Lmax * Cin;
+    float4 sv[UPT];
+    auto stage_load = [&](int cs) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = tid + q * 256, uc = u < UNITS ? u : UNITS - 1;
+            const int row = uc >> 3, c = cs * 32 + 4 * (uc & 7);
+            const int t = t0 + row - PL;
+            const int tc = t < 0 ? 0 : (t >= len ? len - 1 : t);
+            const int cc = c + 4 <= Cin ? c : Cin - 4;
+            float4 v = *reinterpret_cast<const float4*>(xb + (size_t)tc * Cin + cc);
+            if (t != tc || c != cc) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            sv[q] = v;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < UPT; ++q) {
+            const int u = tid + q * 256;
+            if (u >= UNITS) continue;
+            const unsigned h0 = vtts::pack_bf16x2(sv[q].x, sv[q].y), h1 = vtts::pack_bf16x2(sv[q].z, sv[q].w);
+            const unsigned l0 = vtts::pack_bf16x2(sv[q].x - vtts::bf16_lo(h0), sv[q].y - vtts::bf16_hi(h0));
+            const unsigned l1 = vtts::pack_bf16x2(sv[q].z - vtts::bf16_lo(h1), sv[q].w - vtts::bf16_hi(h1));
+            const int o = (u >> 3) * RSB + 4 * (u & 7);
+            *reinterpret_cast<uint2*>(&xs[buf][0][o]) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(&xs[buf][1][o]) = make_uint2(l0, l1);
+        }
+    };
+    // A fragments of one (step, tap): [16-channel half][hi | lo] per m-block, a (step, tap) ahead in a second register set
+    auto load_a = [&](int cs, int j, bf16x8 (&av)[MR][2][2]) {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            const int mb = mb0 + mr < MB ? mb0 + mr : MB - 1;
+            const uint4* __restrict__ ap = wpk + ((((size_t)mb * NCS + cs) * K + j) * 4) * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) av[mr][ks][pl] = __builtin_bit_cast(bf16x8, ap[(ks * 2 + pl) * 64]);
+        }
+    };
+    auto mfma_tap = [&](int buf, int j, const bf16x8 (&av)[MR][2][2]) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bh[NR], bl[NR];
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int o = (l31 + j + 32 * nr) * RSB + 16 * ks + 8 * lh;  // frame t0 + 32 nr + l31 + j - PL, channels 16 ks + 8 lh .. + 7 of the step
+                bh[nr] = *reinterpret_cast<const bf16x8*>(&xs[buf][0][o]);
+                bl[nr] = *reinterpret_cast<const bf16x8*>(&xs[buf][1][o]);
+            }
+            // the small terms first
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mr][ks][1], bh[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mr][ks][0], bl[nr], acc[mr][nr], 0, 0, 0);
+#pragma unroll
+            for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                for (int nr = 0; nr < NR; ++nr)
+                    if (nr == 0 || two) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mr][ks][0], bh[nr], acc[mr][nr], 0, 0, 0);
+        }
+    };
+    bf16x8 avA[MR][2][2], avB[MR][2][2];
+    stage_load(0);
+    if (mine) load_a(0, 0, avA);
+    stage_store(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int cs0 = 0; cs0 < NCS; cs0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cs = cs0 + u;
+            if (cs >= NCS) break;  // uniform
+            if (cs + 1 < NCS) stage_load(cs + 1);
+            if (mine) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const bool last = j + 1 == K;
+                    const int ncs = last ? cs + 1 : cs, nj = last ? 0 : j + 1;
+                    const bool more = ncs < NCS;
+                    if (((u * K + j) & 1) == 0) {
+                        if (more) load_a(ncs, nj, avB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(u, j, avA);
+                    } else {
+                        if (more) load_a(ncs, nj, avA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mfma_tap(u, j, avB);
+                    }
+                }
+            }
+            if (cs + 1 < NCS) {
+                stage_store(u ^ 1);
+                __syncthreads();
+            }
+        }
+    }
+    if (!mine) return;
+    const bool bn = inv != nullptr;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int co = 32 * (mb0 + mr) + 8 * rq + 4 * lh;
+            if (mb0 + mr >= MB || co >= Cout) continue;
             float iv[4] = {1.f, 1.f, 1.f, 1.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4] = {0.f, 0.f, 0.f, 0.f};
             if (bn) {
 #pragma unroll
@@ -1578,6 +1774,28 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
                             }
         });
     }
+    // ... and split into two bf16 terms for nat_conv_x3_k: [mblk][step][tap][16-channel half][hi | lo][lane][8] bf16
+    for (int i = 0; i < 5; ++i) {
+        const std::string mod = "conv1_d" + (i ? "_" + std::to_string(i) : std::string());
+        const int cin = i == 0 ? MEL : PD, cout = i == 4 ? MEL : PD, MB = (cout + 31) / 32, NCS = (cin + 31) / 32;
+        h->add_extra(mod + "#x3", (size_t)MB * NCS * 5 * 4 * 64 * 8 * sizeof(unsigned short), [mod, cin, cout, MB, NCS](const NatModel& m, float* outf) {
+            unsigned short* out = reinterpret_cast<unsigned short*>(outf);
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            for (int mb = 0; mb < MB; ++mb)
+                for (int cs = 0; cs < NCS; ++cs)
+                    for (int j = 0; j < 5; ++j)
+                        for (int ks = 0; ks < 2; ++ks)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 8; ++e) {
+                                    const int c = 32 * cs + 16 * ks + 8 * (lane >> 5) + e, co = 32 * mb + (lane & 31);
+                                    const float w = (c < cin && co < cout) ? W[((size_t)j * cin + c) * cout + co] : 0.0f;
+                                    const unsigned short hi = nat_bf16_rne(w), lo = nat_bf16_rne(w - nat_bf16_to_float(hi));
+                                    const size_t base = ((((size_t)mb * NCS + cs) * 5 + j) * 4 + ks * 2) * 64;
+                                    out[(base + lane) * 8 + e] = hi;
+                                    out[(base + 64 + lane) * 8 + e] = lo;
+                                }
+        });
+    }
     // projection and prenet matrices in [row / 4][col][4] order (nat_dec_proj_prenet_k: one 16-byte load = 4 rows of a column)
     for (const char* l : {"linear", "linear_1", "linear_2"}) {
         const std::string mod = l;
@@ -1627,6 +1845,23 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
     return VTTS_OK;
 }
 VTTS_API void vtts_nat_acoustic_destroy(vtts_nat_acoustic* h) { delete h; }
+VTTS_API int vtts_nat_acoustic_set_option(vtts_nat_acoustic* h, const char* key, int value) {
+    if (!h || !key) return failf(VTTS_ERR_INVALID, "null argument");
+    if (!strcmp(key, "bf16x3")) {
+        if (value != 0 && value != 1) return failf(VTTS_ERR_INVALID, "bf16x3 must be 0 or 1 (got %d)", value);
+        h->x3 = value;
+        return VTTS_OK;
+    }
+    return failf(VTTS_ERR_INVALID, "unknown option '%s' (known: bf16x3)", key);
+}
+VTTS_API int vtts_nat_acoustic_get_option(const vtts_nat_acoustic* h, const char* key, int* value) {
+    if (!h || !key || !value) return failf(VTTS_ERR_INVALID, "null argument");
+    if (!strcmp(key, "bf16x3")) {
+        *value = h->x3;
+        return VTTS_OK;
+    }
+    return failf(VTTS_ERR_INVALID, "unknown option '%s' (known: bf16x3)", key);
+}
 VTTS_API int vtts_nat_acoustic_num_params(const vtts_nat_acoustic* h, int* n) {
     if (!h || !n) return failf(VTTS_ERR_INVALID, "null argument");
     *n = (int)h->arrs.size();
@@ -1796,7 +2031,14 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
             const float *iv = i < 4 ? h->inv(bn) : nullptr, *mv = i < 4 ? h->dev(bn + "/~/mean_ema", "average") : nullptr, *ov = i < 4 ? h->dev(bn, "offset") : nullptr;
             const int act = i < 4 ? (int)NAT_ACT_TANH : (int)NAT_ACT_NONE;
             const float* res = i == 4 ? mel0 + (size_t)r0 * Fmax * MEL : nullptr;
-            if (MB >= 8)
+            const uint4* wx3 = reinterpret_cast<const uint4*>(h->extra(cv + "#x3"));
+            if (h->x3 && MB >= 8)
+                hipLaunchKernelGGL((nat_conv_x3_k<5, 2>), dim3((frames + 63) / 64, (MB + 7) / 8, r1 - r0), dim3(256), 0, ps, cur, nframes_dev + r0, wx3,
+                                   h->dev(cv, "b"), iv, mv, ov, res, dst, Fmax, cin, cout, act, 0);
+            else if (h->x3)
+                hipLaunchKernelGGL((nat_conv_x3_k<5, 1>), dim3((frames + 63) / 64, (MB + 3) / 4, r1 - r0), dim3(256), 0, ps, cur, nframes_dev + r0, wx3,
+                                   h->dev(cv, "b"), iv, mv, ov, res, dst, Fmax, cin, cout, act, 0);
+            else if (MB >= 8)
                 hipLaunchKernelGGL((nat_conv_mfma_k<5, 2>), dim3((frames + 63) / 64, (MB + 7) / 8, r1 - r0), dim3(256), 0, ps, cur, nframes_dev + r0, wpk,
                                    h->dev(cv, "b"), iv, mv, ov, res, dst, Fmax, cin, cout, act, 0);
             else

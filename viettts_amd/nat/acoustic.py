@@ -152,6 +152,15 @@ class AcousticModel:
                                                                                   _ptr(keep), C.c_void_p(stream.cuda_stream)))
         return keep
 
+    def set_option(self, key: str, value: int) -> None:
+        """``"bf16x3"``: 1 = the postnet's matrix products as three bf16 x bf16 terms on the bf16 matrix pipe (include/vtts_nat.h); 0 = fp32 (default)."""
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_set_option(self._h, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_get_option(self._h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def wait_group(self, group: int, stream: Optional[torch.cuda.Stream] = None) -> None:
         """Make ``stream`` (default: torch's current stream) wait until the rows of ``group`` of the last ``group_row0`` call are complete."""
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
