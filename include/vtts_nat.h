@@ -94,10 +94,12 @@ int vtts_nat_acoustic_pack(vtts_nat_acoustic* h, void* dev_blob, size_t blob_byt
 int vtts_nat_acoustic_bind_packed(vtts_nat_acoustic* h, void* dev_blob, size_t blob_bytes);
 int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B, int Lmax, int Fmax, size_t* bytes);
 /* Options (defaults in brackets):
- *   "bf16x3" [0]  1 = the matrix products of the postnet as three bf16 x bf16 terms on the bf16 matrix pipe (every operand v = v0 + v1,
- *                 v0 = bf16(v), v1 = bf16(v - v0); x * w ~ x1 w0 + x0 w1 + x0 w0, fp32 accumulation): the mel moves by ~1e-5 of its
- *                 range (tests/test_gpu_nat.py) and the postnet runs 2-3 x faster.  The default keeps every product in fp32 — the mode the
- *                 parity tests against the reference pin at 5e-5.  For callers whose vocoder is bf16-class anyway.
+ *   "bf16x3" [0]  1 = the matrix products of the decoder's LSTM steps, of the gate GEMM and of the postnet as three bf16 x bf16 terms on the
+ *                 bf16 matrix pipe (every operand v = v0 + v1, v0 = bf16(v), v1 = bf16(v - v0); x * w ~ x1 w0 + x0 w1 + x0 w0, fp32
+ *                 accumulation; the decoder state is kept split, the cell states, the projection and the prenet stay fp32): the mel moves
+ *                 by ~1e-5 of its range (tests/test_gpu_nat.py) and the acoustic model runs a third faster.  The default keeps every
+ *                 product in fp32 — the mode the parity tests against the reference pin at 5e-5.  For callers whose vocoder is
+ *                 bf16-class anyway.  The token encoders and the duration model are fp32 in both modes (integer frame counts).
  * Unknown keys and out-of-range values return VTTS_ERR_INVALID. */
 int vtts_nat_acoustic_set_option(vtts_nat_acoustic* h, const char* key, int value);
 int vtts_nat_acoustic_get_option(const vtts_nat_acoustic* h, const char* key, int* value);

@@ -409,9 +409,10 @@ def test_acoustic_wide_batch_rows_equal_rows_alone(acoustic):
 
 
 def test_acoustic_bf16x3_option(acoustic, capsys):
-    """Option "bf16x3" (include/vtts_nat.h): the postnet's products as three bf16 x bf16 terms on the bf16 matrix pipe.  The mel stays within
-    2e-4 of its range of the fp32 mode's (observed ~1e-5) and within the fp32 mode's own bound of the fp64 oracle; rows stay independent of
-    their batch; the option reads back, and an unknown key is refused."""
+    """Option "bf16x3" (include/vtts_nat.h): the matrix products of the decoder's LSTM steps, of the gate GEMM and of the postnet as three
+    bf16 x bf16 terms on the bf16 matrix pipe.  The mel stays within 2e-4 of its range of the fp32 mode's (observed ~1e-5) and within the fp32
+    mode's own bound of the fp64 oracle; rows stay independent of their batch (narrow and wide batches, the grouped hand-over); the option
+    reads back, and an unknown key is refused."""
     m, P, S = acoustic
     cases = [_case(31, 9), _case(32, 30), _case(33, 1), _case(34, 17)]
     seeds = [61, 62, 63, 64]
@@ -433,6 +434,26 @@ def test_acoustic_bf16x3_option(acoustic, capsys):
         masks = no.threefry_keep_masks(sd, nf, 256)
         orc = no.acoustic_inference(P, S, np.array(tok), dur, nf, prenet_masks=lambda f: (masks[f, 0], masks[f, 1]))
         assert np.abs(g - orc).max() < 5e-4 * max(1.0, np.abs(orc).max())
+    # a wide batch (two 32-sentence tiles per wave), sentences that finish early, the grouped hand-over
+    wide = sorted((_case(940 + i, 2 + (i * 7) % 23) for i in range(41)), key=lambda c: -c[2])
+    wseeds = [7000 + i for i in range(41)]
+    wargs = ([c[0] for c in wide], [c[1] for c in wide], [c[2] for c in wide])
+    wref = m(*wargs, dropout_seeds=wseeds)
+    m.set_option("bf16x3", 1)
+    try:
+        wgot = m(*wargs, dropout_seeds=wseeds)
+        for i in (0, 20, 40):
+            assert np.array_equal(m([wide[i][0]], [wide[i][1]], [wide[i][2]], dropout_seeds=[wseeds[i]])[0], wgot[i]), i
+        grouped = m(*wargs, dropout_seeds=wseeds, to_host=False, group_row0=[0, 9, 25, 41])
+        import torch
+
+        torch.cuda.synchronize()
+        for i in (0, 20, 40):
+            assert np.array_equal(grouped[i, : wide[i][2]].cpu().numpy(), wgot[i]), i
+    finally:
+        m.set_option("bf16x3", 0)
+    for g, r in zip(wgot, wref):
+        worst = max(worst, float(np.abs(g - r).max()) / max(1.0, float(np.abs(r).max())))
     with capsys.disabled():
         print(f"[acoustic model, bf16x3 option vs fp32 mode] max|d mel| / range {worst:.2e}")
     assert 0.0 < worst < 2e-4

@@ -247,7 +247,7 @@ static inline float nat_bf16_to_float(unsigned short h) {
 }
 struct vtts_nat_acoustic : NatModel {
     vtts_nat_acoustic_cfg cfg;
-    int x3 = 0;  // option "bf16x3": the postnet's convolutions as three bf16 x bf16 terms on the bf16 matrix pipe (nat_conv_x3_k)
+    int x3 = 0;  // option "bf16x3": LSTM steps, gate GEMM and postnet as three bf16 x bf16 terms per product on the bf16 matrix pipe
     // forward_groups(): the postnet of a group of rows runs on `side` as soon as the decoder has produced the group's last frame
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gates = nullptr;
@@ -1356,6 +1356,140 @@ __global__ __launch_bounds__(512) void nat_dec_persist_k(NatPersistArgs a) {
 }
 #endif  // VTTS_NAT_PERSIST
 
+// ---- the decoder step with the option "bf16x3": the gate sums as three bf16 x bf16 terms per product on the bf16 matrix pipe ----------------
+// The state lives in HBM already split: Zx[parity][hi | lo][row / 8][Bp][8] bf16 (rows [p | h1 | h2]; h = hi + lo to 16 mantissa bits), so that a
+// lane's B fragment of v_mfma_f32_32x32x16_bf16 (sentence lane % 32, rows 16 step + 8 (lane / 32) .. + 7) is one 16-byte load per plane; the
+// weights are split at pack time ("…#x3": [slice][K / 16][hi | lo][lane][8] bf16, the fp32 fragments' bytes).  Per 16 rows and 32-sentence tile
+// three matrix instructions of 32 cycles instead of eight of 64; everything around them (the hoisted gates G in fp32, the tree over the K
+// shares, the cell update in fp32 registers, c in fp32) is the fp32 step's.  Every output element still depends on its own sentence only.
+__device__ __forceinline__ size_t nat_zxidx(int row, int b, int Bp) { return ((size_t)(row >> 3) * Bp + b) * 8 + (row & 7); }
+struct NatLstmX3Ops {
+    const unsigned short* zc;  // this frame's parity (rows [0, KA) are read from it), plane 0; plane 1 at + plane
+    const unsigned short* zp;  // the previous frame's (rows [KA, K))
+    size_t plane;              // bf16 elements between the hi and the lo plane
+    const uint4* wpk;          // [slice][K / 16][2][64] x 16 bytes
+    const float* gin;          // this step's hoisted gate pre-activations (NatLstmOps::gin)
+    size_t gpitch;
+    float* cst;                // [H][Bp] fp32
+    unsigned short* hout;      // zc, plane 0: the new hidden state goes to rows out_row0 + unit
+    int out_row0;
+};
+template <int NT, int KW>
+__global__ __launch_bounds__(64 * KW) void nat_dec_lstm_x3_k(NatLstmX3Ops ops, int KA, int K, const int* __restrict__ nframes, int f, int B, int Bp, int H) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    using vtts::bf16x8;
+    constexpr int PD = 3;
+    __shared__ float red[KW / 2][NT][16][64];
+    const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int slice = blockIdx.x, b0 = blockIdx.y * 32 * NT;
+    bool live[NT];
+    bool any = false;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int b = b0 + 32 * nt + l31;
+        live[nt] = b < B && f < nframes[b < B ? b : B - 1];
+        any = any || live[nt];
+    }
+    if (__ballot(any) == 0ull) return;
+    const int NST = K / 16, NWMAX = (NST + KW - 1) / KW, st_lo = kw * NWMAX;
+    const int NW = st_lo >= NST ? 0 : (NST - st_lo < NWMAX ? NST - st_lo : NWMAX);
+    f32x16 acc[NT];
+    if (kw == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int b = b0 + 32 * nt + l31;
+            const float4* __restrict__ gp = reinterpret_cast<const float4*>(ops.gin + (size_t)(b < B ? b : B - 1) * ops.gpitch + (size_t)(2 * slice + lh) * 16);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 g4 = gp[rq];
+                acc[nt][4 * rq + 0] = g4.x;
+                acc[nt][4 * rq + 1] = g4.y;
+                acc[nt][4 * rq + 2] = g4.z;
+                acc[nt][4 * rq + 3] = g4.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+    }
+    uint4 wv[PD][2], xv[PD][NT][2];
+    const uint4* __restrict__ wsl = ops.wpk + (size_t)slice * NST * 2 * 64 + lane;
+    auto load_st = [&](int st, int slot) {
+        if (st >= NST) st = NST - 1;  // tail: an in-bounds re-read, never used
+        wv[slot][0] = wsl[(size_t)(2 * st) * 64];
+        wv[slot][1] = wsl[(size_t)(2 * st + 1) * 64];
+        const unsigned short* __restrict__ zs = (16 * st < KA ? ops.zc : ops.zp) + ((size_t)(2 * st + lh) * Bp + b0 + l31) * 8;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            xv[slot][nt][0] = *reinterpret_cast<const uint4*>(zs + (size_t)(32 * nt) * 8);
+            xv[slot][nt][1] = *reinterpret_cast<const uint4*>(zs + ops.plane + (size_t)(32 * nt) * 8);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PD; ++j) load_st(st_lo + j, j);
+#pragma nounroll
+    for (int i0 = 0; i0 < NW; i0 += PD) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            if (i0 + j >= NW) break;  // wave-uniform
+            const bf16x8 whi = __builtin_bit_cast(bf16x8, wv[j][0]), wlo = __builtin_bit_cast(bf16x8, wv[j][1]);
+            // the small terms first
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, __builtin_bit_cast(bf16x8, xv[j][nt][0]), acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, __builtin_bit_cast(bf16x8, xv[j][nt][1]), acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whi, __builtin_bit_cast(bf16x8, xv[j][nt][0]), acc[nt], 0, 0, 0);
+            const int nx = i0 + j + PD;
+            load_st(nx < NW ? st_lo + nx : NST, j);
+        }
+    }
+    // fixed-order tree over the K shares, then the shared-out cell update (as in nat_dec_lstm_k)
+#pragma unroll
+    for (int half = KW / 2; half >= 1; half >>= 1) {
+        if (kw >= half && kw < 2 * half) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[kw - half][nt][r][lane] = acc[nt][r];
+        }
+        __syncthreads();
+        if (kw < half) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] += red[kw][nt][r][lane];
+        }
+        if (half > 1) __syncthreads();
+    }
+    if (kw == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[0][nt][r][lane] = acc[nt][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int blk = 0; blk < NT * 4; ++blk) {
+        if (blk % KW != kw) continue;  // wave-uniform
+        const int nt = blk / 4, rq = blk % 4;
+        if (!live[nt]) continue;
+        const float gi = red[0][nt][4 * rq + 0][lane], gg = red[0][nt][4 * rq + 1][lane], gf = red[0][nt][4 * rq + 2][lane], go = red[0][nt][4 * rq + 3][lane];
+        const int b = b0 + 32 * nt + l31, u = 8 * slice + 2 * rq + lh;
+        float c = ops.cst[(size_t)u * Bp + b];
+        c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
+        ops.cst[(size_t)u * Bp + b] = c;
+        const float hv = sigmoidf_(go) * tanhf(c);
+        const unsigned hp = vtts::pack_bf16x2(hv, 0.0f);
+        const unsigned lp = vtts::pack_bf16x2(hv - vtts::bf16_lo(hp), 0.0f);
+        const size_t o = nat_zxidx(ops.out_row0 + u, b, Bp);
+        ops.hout[o] = (unsigned short)(hp & 0xffffu);
+        ops.hout[o + ops.plane] = (unsigned short)(lp & 0xffffu);
+    }
+}
+
 // TokenEncoder's two LSTMs (model.py:39-46) on the same batched step kernel: hk.LSTM over [x_t ; h] is the decoder step with
 // KA = D input rows and KB = D hidden rows, and all sentences advance together (one launch per token position steps BOTH
 // directions: blockIdx.z).  The step kernel wants its operands k-major with the sentences contiguous, so
@@ -1497,11 +1631,12 @@ __global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsig
 // mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 into the other parity's state.  One
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
+template <bool X3>  // X3: the state is the bf16x3 step's (two bf16 planes, nat_zxidx; `plane` elements apart); h = hi + lo exactly, p is split on its way out
 __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext,
                                                               const int* __restrict__ nframes, const float4* __restrict__ f1, const float4* __restrict__ f2,
                                                               const float4* __restrict__ wp, const float* __restrict__ bp,
                                                               const unsigned char* __restrict__ keep, float* __restrict__ mel, int f, int B, int Bp,
-                                                              int Fmax, int PN, int H, int MEL) {
+                                                              int Fmax, int PN, int H, int MEL, size_t plane) {
     extern __shared__ float4 sq[];
     float4* hs = sq;              // [2H]   h1 ; h2 of the 4 sentences
     float4* part = hs + 2 * H;    // [1024] partial sums of the product in flight
@@ -1516,9 +1651,18 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         any = any || f < nf[s];
     }
     if (!any) return;
+#pragma clang loop vectorize(disable)  // (it would pair the hi + lo additions of two rows into v_pk_add_f32: build.py)
     for (int k = g; k < 2 * H; k += 1024) {
-        const float* __restrict__ zr = zcur + nat_zidx(PN + k, b0, Bp);  // state rows [p | h1 | h2]; the 4 sentences of a row are 16 bytes apart
-        hs[k] = make_float4(zr[0], zr[4], zr[8], zr[12]);
+        if constexpr (X3) {
+            const unsigned short* __restrict__ zr = reinterpret_cast<const unsigned short*>(zcur) + nat_zxidx(PN + k, b0, Bp);  // sentences 8 elements apart
+            float v[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = __builtin_bit_cast(float, (unsigned)zr[8 * s] << 16) + __builtin_bit_cast(float, (unsigned)zr[plane + 8 * s] << 16);
+            hs[k] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            const float* __restrict__ zr = zcur + nat_zidx(PN + k, b0, Bp);  // state rows [p | h1 | h2]; the 4 sentences of a row are 16 bytes apart
+            hs[k] = make_float4(zr[0], zr[4], zr[8], zr[12]);
+        }
     }
     __syncthreads();
     // out[col] (4 sentences) = sum over chunk `ch` of rows [ch*per, (ch+1)*per) of src[row] * w[row][col]
@@ -1578,8 +1722,20 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     __syncthreads();
     if (g < PN) {
         const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
-        float* __restrict__ zw = znext + nat_zidx(g, b0, Bp);
-        zw[0] = r.x; zw[4] = r.y; zw[8] = r.z; zw[12] = r.w;
+        if constexpr (X3) {
+            unsigned short* __restrict__ zw = reinterpret_cast<unsigned short*>(znext) + nat_zxidx(g, b0, Bp);
+            const float v[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const unsigned hp = vtts::pack_bf16x2(v[s], 0.0f);
+                const unsigned lp = vtts::pack_bf16x2(v[s] - vtts::bf16_lo(hp), 0.0f);
+                zw[8 * s] = (unsigned short)(hp & 0xffffu);
+                zw[plane + 8 * s] = (unsigned short)(lp & 0xffffu);
+            }
+        } else {
+            float* __restrict__ zw = znext + nat_zidx(g, b0, Bp);
+            zw[0] = r.x; zw[4] = r.y; zw[8] = r.z; zw[12] = r.w;
+        }
     }
 }
 
@@ -1815,6 +1971,29 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
     const int E = 2 * D;
     h->add_lstm_mfma("lstm/linear", PN + H, H, [E](int zr) { return E + zr; });
     h->add_lstm_mfma("lstm_1/linear", PN + H + H, H, [E](int zr) { return E + zr; });
+    // ... and split into two bf16 terms for nat_dec_lstm_x3_k: [slice][K / 16][hi | lo][lane][8] bf16, element i of lane = the bf16 term of
+    // W[E + 16*step + 8*(lane/32) + i][gate*H + 8*slice + unit], (unit, gate) = ((lane%32)/4, (lane%32)%4)
+    for (int l = 0; l < 2; ++l) {
+        const std::string mod = l ? "lstm_1/linear" : "lstm/linear";
+        const int K = l ? PN + 2 * H : PN + H;
+        h->add_extra(mod + "#x3", (size_t)K * 4 * H * sizeof(float), [mod, K, H, E](const NatModel& m, float* outf) {
+            unsigned short* out = reinterpret_cast<unsigned short*>(outf);
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            const int NST = K / 16;
+            for (int sl = 0; sl < H / 8; ++sl)
+                for (int st = 0; st < NST; ++st)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int mrow = lane & 31, lh = lane >> 5, col = (mrow & 3) * H + 8 * sl + (mrow >> 2);
+                        for (int i = 0; i < 8; ++i) {
+                            const float w = W[(size_t)(E + 16 * st + 8 * lh + i) * 4 * H + col];
+                            const unsigned short hi = nat_bf16_rne(w), lo = nat_bf16_rne(w - nat_bf16_to_float(hi));
+                            const size_t base = ((size_t)sl * NST + st) * 2 * 64;
+                            out[(base + lane) * 8 + i] = hi;
+                            out[(base + 64 + lane) * 8 + i] = lo;
+                        }
+                    }
+        });
+    }
     for (const char* l : {"lstm/linear", "lstm_1/linear"}) {
         const std::string mod = l;
         const int G4 = 4 * H, MB = G4 / 32, NCS = E / 32;
@@ -1835,6 +2014,22 @@ VTTS_API int vtts_nat_acoustic_create(const vtts_nat_acoustic_cfg* cfg, int devi
         h->add_extra(mod + "#condb", (size_t)G4 * sizeof(float), [mod, G4, hcol](const NatModel& m, float* out) {
             const std::vector<float>& bv = m.arrs[m.find(mod, "b")].host;
             for (int cp = 0; cp < G4; ++cp) out[cp] = bv[hcol(cp)];
+        });
+        h->add_extra(mod + "#cond#x3", (size_t)MB * NCS * 4 * 64 * 8 * sizeof(unsigned short), [mod, E, G4, MB, NCS, hcol](const NatModel& m, float* outf) {
+            unsigned short* out = reinterpret_cast<unsigned short*>(outf);  // the same rows for nat_conv_x3_k: [mblk][step][16-channel half][hi | lo][lane][8] bf16
+            const std::vector<float>& W = m.arrs[m.find(mod, "w")].host;
+            for (int mb = 0; mb < MB; ++mb)
+                for (int cs = 0; cs < NCS; ++cs)
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int c = 32 * cs + 16 * ks + 8 * (lane >> 5) + e, cp = 32 * mb + (lane & 31);
+                                const float w = W[(size_t)c * G4 + hcol(cp)];
+                                const unsigned short hi = nat_bf16_rne(w), lo = nat_bf16_rne(w - nat_bf16_to_float(hi));
+                                const size_t base = (((size_t)mb * NCS + cs) * 4 + ks * 2) * 64;
+                                out[(base + lane) * 8 + e] = hi;
+                                out[(base + 64 + lane) * 8 + e] = lo;
+                            }
         });
         h->add_extra(mod + "#zerob", (size_t)G4 * sizeof(float), [G4](const NatModel&, float* out) {  // the token-rows GEMM adds no bias (the mix does)
             for (int cp = 0; cp < G4; ++cp) out[cp] = 0.0f;
@@ -2058,12 +2253,17 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
         // frames [0, 64) here and for the rest beside the first 64 steps
         const int MBG = G4 / 32;
         if (G4 % 1024 != 0) return failf(VTTS_ERR_INVALID, "decoder_dim %d: the gate mix wants 4 * decoder_dim in multiples of 1024", H);
-        hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
-                           reinterpret_cast<const float4*>(h->extra("lstm/linear#cond")), h->extra("lstm/linear#zerob"), nullptr, nullptr, nullptr, nullptr, EG1, Lmax,
-                           E, G4, (int)NAT_ACT_NONE, 0);
-        hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
-                           reinterpret_cast<const float4*>(h->extra("lstm_1/linear#cond")), h->extra("lstm_1/linear#zerob"), nullptr, nullptr, nullptr, nullptr, EG2,
-                           Lmax, E, G4, (int)NAT_ACT_NONE, 0);
+        for (int l = 0; l < 2; ++l) {
+            const std::string mod = l ? "lstm_1/linear" : "lstm/linear";
+            if (h->x3)
+                hipLaunchKernelGGL((nat_conv_x3_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
+                                   reinterpret_cast<const uint4*>(h->extra(mod + "#cond#x3")), h->extra(mod + "#zerob"), nullptr, nullptr, nullptr, nullptr,
+                                   l ? EG2 : EG1, Lmax, E, G4, (int)NAT_ACT_NONE, 0);
+            else
+                hipLaunchKernelGGL((nat_conv_mfma_k<1, 2>), dim3((Lmax + 63) / 64, (MBG + 7) / 8, B), dim3(256), 0, s, enc, lengths_dev,
+                                   reinterpret_cast<const float4*>(h->extra(mod + "#cond")), h->extra(mod + "#zerob"), nullptr, nullptr, nullptr, nullptr,
+                                   l ? EG2 : EG1, Lmax, E, G4, (int)NAT_ACT_NONE, 0);
+        }
         const size_t mlds = ((size_t)(Lmax + 3) / 4 * 4 + (size_t)Lmax * NAT_MIX_FT) * sizeof(float);
         if (mlds > 48 * 1024)
             HIP_TRYN(hipFuncSetAttribute(reinterpret_cast<const void*>(&nat_gates_mix_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
@@ -2141,14 +2341,36 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
             }
         }
 #endif
+        // option "bf16x3": the split-state step (nat_dec_lstm_x3_k) where its 16-row steps divide the row blocks; the state's two parities hold
+        // two bf16 planes each (the same bytes as the fp32 rows)
+        const bool dx3 = h->x3 && PN % 16 == 0 && H % 16 == 0 && ((PN + H) / 16) % 8 == 0 && ((PN + 2 * H) / 16) % 8 == 0;
+        const size_t zplane = (size_t)ZW * Bp;  // bf16 elements per plane
+        const uint4* w1x = reinterpret_cast<const uint4*>(h->extra("lstm/linear#x3"));
+        const uint4* w2x = reinterpret_cast<const uint4*>(h->extra("lstm_1/linear#x3"));
+        auto lstm_x3 = [&](unsigned short* zcx, const unsigned short* zpx, int KA, int K, const uint4* w, const float* gin, float* cst, int out_row0, int f) {
+            const NatLstmX3Ops o{zcx, zpx, zplane, w, gin + (size_t)f * G4, (size_t)Fmax * G4, cst, zcx, out_row0};
+            if (wide) hipLaunchKernelGGL((nat_dec_lstm_x3_k<2, 8>), lgrid, dim3(512), 0, s, o, KA, K, nframes_dev, f, B, Bp, H);
+            else hipLaunchKernelGGL((nat_dec_lstm_x3_k<1, 8>), lgrid, dim3(512), 0, s, o, KA, K, nframes_dev, f, B, Bp, H);
+        };
         for (int f = 0; f < Fmax && !persist; ++f) {
             if (f == 64) HIP_TRYN(hipStreamWaitEvent(s, h->ev_gates, 0));
             float* zc = Z[f & 1];
             float* zp = Z[(f + 1) & 1];
+            if (dx3) {
+                unsigned short* zcx = reinterpret_cast<unsigned short*>(zc);
+                const unsigned short* zpx = reinterpret_cast<const unsigned short*>(zp);
+                lstm_x3(zcx, zpx, PN, PN + H, w1x, G1, c1, PN, f);
+                lstm_x3(zcx, zpx, PN + H, PN + 2 * H, w2x, G2, c2, PN + H, f);
+                hipLaunchKernelGGL(nat_dec_proj_prenet_k<true>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f,
+                                   B, Bp, Fmax, PN, H, MEL, zplane);
+                rc = group_handover(f + 1);
+                if (rc) return rc;
+                continue;
+            }
             lstm(zc, PN, zp + (size_t)PN * Bp, w1, G1, c1, zc + (size_t)PN * Bp, f);
             lstm(zc, PN + H, zp + (size_t)(PN + H) * Bp, w2, G2, c2, zc + (size_t)(PN + H) * Bp, f);
-            hipLaunchKernelGGL(nat_dec_proj_prenet_k, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f, B, Bp,
-                               Fmax, PN, H, MEL);
+            hipLaunchKernelGGL(nat_dec_proj_prenet_k<false>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f, B,
+                               Bp, Fmax, PN, H, MEL, (size_t)0);
             rc = group_handover(f + 1);  // under the remaining decoder steps
             if (rc) return rc;
         }
