@@ -399,7 +399,9 @@ def main():
     pipe = None
     if not args.no_rtf and args.dtype == "bf16":
         try:
-            pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier)
+            # the vocoder here is the bf16 engine (~1e-2 of a sample's range), so the acoustic model runs with its bf16x3 option (1e-5 of the mel's
+            # range: include/vtts_nat.h); `acoustic_fp32` below = the same job with every acoustic product in fp32 (the mode pinned to the reference at 5e-5)
+            pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier, nat_bf16x3=True)
         except Exception as e:  # a side measurement must not take the headline line down with it
             pipe = {"error": f"{type(e).__name__}: {e}"}
         if n_gpus > 1:  # the ranks agree on whether to combine (a failed rank would otherwise leave the others in a collective)
@@ -425,7 +427,13 @@ def main():
             # the opt-in overlapped schedule (acoustic model and generator side by side, mel handed over in 6 groups), same process: what it gains
             # depends on how the runtime maps the streams to hardware queues (viettts_amd/pipeline.py), so it is reported, not assumed
             try:
-                po = pipeline_256(256, gen, info.rank, n_gpus, barrier, overlap_groups=6)
+                pf = pipeline_256(256, gen, info.rank, n_gpus, barrier)
+                pipe["acoustic_fp32"] = {"acoustic_model_ms": pf["acoustic_model_ms"], "generator_ms": pf["generator_ms"], "total_ms": pf["total_ms"],
+                                         "samples_per_s": pf["samples"] / (pf["total_ms"] * 1e-3)}
+            except Exception as e:
+                pipe["acoustic_fp32"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                po = pipeline_256(256, gen, info.rank, n_gpus, barrier, overlap_groups=6, nat_bf16x3=True)
                 pipe["overlapped_schedule"] = {"overlap_groups": po["overlap_groups"], "total_ms": po["total_ms"], "generator_ms": po["generator_ms"],
                                                "acoustic_enqueue_ms": po["acoustic_enqueue_ms"]}
             except Exception as e:

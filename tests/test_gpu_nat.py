@@ -264,8 +264,10 @@ def test_pipeline_sharded_equals_unsharded(model, acoustic):
         gen.close()
 
 
-def test_pipeline_waveforms_equal_each_sentence_alone_and_the_oracle(model, acoustic, capsys):
-    """What bench.py's ``pipeline_256`` leg runs, against something other than itself.  12 sentences of the reference's demo transcript
+@pytest.mark.parametrize("nat_bf16x3", [False, True], ids=["acoustic-fp32", "acoustic-bf16x3"])
+def test_pipeline_waveforms_equal_each_sentence_alone_and_the_oracle(model, acoustic, capsys, nat_bf16x3):
+    """What bench.py's ``pipeline_256`` leg runs (with the acoustic model's bf16x3 option, as the bench's headline pipeline number, and without),
+    against something other than itself.  12 sentences of the reference's demo transcript
     (token ids pinned to the reference's text2tokens: tests/test_frontend_cpu.py) through ``synthesize_sentences`` — length-sorted
     rows, masks seeded by the global sentence index, the generator's ragged passes, the pinned read-back; with the acoustic model and
     the generator overlapped in groups (the default for large shards) and one after the other:
@@ -291,6 +293,7 @@ def test_pipeline_waveforms_equal_each_sentence_alone_and_the_oracle(model, acou
     params = synthetic_params(V1, 4321, "scaled")
     gen = Generator(V1, device="cuda:0", dtype="bf16")
     gen.load_params(params)
+    am.set_option("bf16x3", int(nat_bf16x3))
     try:
         tm = {}
         over = synthesize_sentences(sents, dm, am, gen, silence_duration=sil, dropout_seed=seed, overlap_groups=3, timing=tm)
@@ -326,8 +329,10 @@ def test_pipeline_waveforms_equal_each_sentence_alone_and_the_oracle(model, acou
             worst_e, worst_snr = max(worst_e, e), min(worst_snr, snr)
             assert e < 0.03 and snr > 35.0, (i, e, snr)
         with capsys.disabled():
-            print(f"\n[pipeline vs the oracle chain, 8 sentences, {sum(serial[i].shape[0] for i in short)} samples] worst max|dy| {worst_e:.3e}, worst SNR {worst_snr:.1f} dB")
+            print(f"\n[pipeline ({'bf16x3' if nat_bf16x3 else 'fp32'} acoustic model) vs the oracle chain, 8 sentences, "
+                  f"{sum(serial[i].shape[0] for i in short)} samples] worst max|dy| {worst_e:.3e}, worst SNR {worst_snr:.1f} dB")
     finally:
+        am.set_option("bf16x3", 0)
         gen.close()
 
 
