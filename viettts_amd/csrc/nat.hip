@@ -1628,6 +1628,9 @@ __global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsig
     }
 }
 
+// (Round 4 measured two restructurings of this kernel and kept neither: every weight fragment loaded ahead of its use, 16.3-18.7 -> 19.4 us, and
+// 4-5 adjacent columns per thread to cut the LDS operand reads by four, 16.0 -> 20.0 us — the step is bound by one CU streaming the three
+// matrices' 670 KB through its vector-memory path, ~5 us, plus three dependent phases: profiles/r04_e_nat_decoder_findings.md.)
 // mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 into the other parity's state.  One
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
