@@ -461,7 +461,12 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #endif
 template <int KS> using RB32 = RBTile<32, KS, KS == 3 ? VTTS_RB32K3_W : VTTS_RB32_W, 1, VTTS_RB32_WN, 3, KS == 3 ? VTTS_RB32K3_WG : VTTS_RB32_WG>;
 template <int KS> using RB64 = RBTile<64, KS, VTTS_RB64_W, 1, VTTS_RB64_WN, 3, VTTS_RB64_WG>;
-template <int KS> using RB128 = RBTile<128, KS, 128, 2, 2, 3, 2>;
+#ifndef VTTS_RB128_W  // A/B (round 4, fuse = 3): a 256-step window on eight waves (one workgroup per CU, 9 % margin) 3.08 ms, the 128-step one (two per CU, 19 %) 3.12, three pair launches 2.88
+#define VTTS_RB128_W 128
+#define VTTS_RB128_WN 2
+#define VTTS_RB128_WG 2
+#endif
+template <int KS> using RB128 = RBTile<128, KS, VTTS_RB128_W, 2, VTTS_RB128_WN, 3, VTTS_RB128_WG>;
 constexpr bool RB64_ALL_K = RB64<11>::LDS_BYTES * VTTS_RB64_WG <= 160 * 1024 && VTTS_RB64_W - 2 * 60 >= 128;  // k = 7, 11 too once the window is wide enough
 
 template <class T>
