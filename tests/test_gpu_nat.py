@@ -199,6 +199,16 @@ def test_text2mel_equals_the_reference_code_executed(tmp_path, monkeypatch):
             err = float(np.abs(mel[0].astype(np.float64) - want).max())
             print(f"[text2mel vs the reference's code, case {ci}: {want.shape[0]} frames] max|d mel| {err:.2e} (|mel| max {np.abs(want).max():.2f})")
             assert err < 5e-5  # observed 3e-6
+            # ... and with the acoustic model's bf16x3 option (include/vtts_nat.h): the same frames, the mel inside the SAME bar (observed 1.6e-5)
+            am = t2m._ACOUSTIC_MODEL
+            am.set_option("bf16x3", 1)
+            try:
+                mel3 = t2m.text2mel(text, lexicon, sil)
+            finally:
+                am.set_option("bf16x3", 0)
+            err3 = float(np.abs(mel3[0].astype(np.float64) - want).max())
+            print(f"[... with the bf16x3 option] max|d mel| {err3:.2e}")
+            assert mel3.shape == mel.shape and err3 < 5e-5
     finally:
         t2m.set_duration_model(None)
         t2m.set_acoustic_model(None)
