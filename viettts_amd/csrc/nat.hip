@@ -854,7 +854,7 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     // a cold L2 at every launch: 17.5 MB of misses per step, PMC passes in profiles/r04_e_nat_decoder_findings.md); the launches use SL = 1.
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     static_assert(KW == 1 || KW == 2 || KW == 4 || KW == 8, "tree reduction");
-    __shared__ float red[KW > 1 ? KW / 2 : 1][SL][NT][16][64];
+    __shared__ float red[KW][SL][NT][16][64];  // every wave's share of the gate sums
     const NatLstmOps& ops = blockIdx.z ? ops1 : ops0;
     const float* __restrict__ inA = ops.inA;
     const float* __restrict__ inB = ops.inB;
@@ -875,6 +875,15 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     if (__ballot(any) == 0ull) return;  // every sentence of these tiles has all its frames (same for all waves)
     const int NIT = (KA + KB) / 8, NWMAX = (NIT + KW - 1) / KW, it_lo = kw * NWMAX;
     const int NW = it_lo >= NIT ? 0 : (NIT - it_lo < NWMAX ? NIT - it_lo : NWMAX);  // this wave's iterations [it_lo, it_lo + NW)
+    // this wave's cell-update blocks ((slice, sentence tile, unit pair) kw, kw + KW, ...): their cell states are requested now, a kernel's length
+    // before they are needed (round 4: loaded after the reduction they were ~1 us of every step)
+    constexpr int NBLK = (SL * NT * 4 + KW - 1) / KW;
+    float cold[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) {
+        const int blk = kw + q * KW, sl = blk / (NT * 4), nt = (blk / 4) % NT, rq = blk % 4;
+        cold[q] = blk < SL * NT * 4 ? cst[(size_t)(8 * (slice0 + sl) + 2 * rq + lh) * Bp + b0 + 32 * nt + l31] : 0.0f;
+    }
     f32x16 acc[SL][NT][2];
     if (ops.gin != nullptr && kw == 0) {
         // the sum starts from the hoisted part (bias + the inputs known ahead of the loop, themselves an MFMA chain in k order)
@@ -957,64 +966,47 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[sl][nt][0][r] += acc[sl][nt][1][r];
-    // fixed-order tree over the K shares: waves [half, 2*half) hand their sums to waves [0, half)
+    // every wave leaves its share of the sums in LDS; after ONE barrier a wave adds the KW shares of its own cell-update blocks in wave order
+    // (round 4: a three-level tree with a barrier per level cost ~0.5 us of every step)
+    if constexpr (KW > 1) {
 #pragma unroll
-    for (int half = KW / 2; half >= 1; half >>= 1) {
-        if (kw >= half && kw < 2 * half) {
+        for (int sl = 0; sl < SL; ++sl)
 #pragma unroll
-            for (int sl = 0; sl < SL; ++sl)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[kw - half][sl][nt][r][lane] = acc[sl][nt][0][r];
-        }
+                for (int r = 0; r < 16; ++r) red[kw][sl][nt][r][lane] = acc[sl][nt][0][r];
         __syncthreads();
-        if (kw < half) {
-#pragma unroll
-            for (int sl = 0; sl < SL; ++sl)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[sl][nt][0][r] += red[kw][sl][nt][r][lane];
-        }
-        if (half > 1) __syncthreads();
     }
-    // The cell update (3 sigmoids + 2 tanh per (unit, sentence): ~1000 VALU instructions per lane for a wave's 8 pairs) is shared out: wave 0
-    // hands the gate sums to the workgroup through LDS and wave w takes the (slice, sentence tile, unit pair) blocks w, w + KW, ...  Round 2 left
-    // it to wave 0 alone while the other seven idled: ~2.5 us of every 22 us step.  The same operations on the same values: the same bits.
-    auto cell_update = [&](int sl, int nt, int rq, float gi, float gg, float gf, float go) {
+    // The cell update (3 sigmoids + 2 tanh per (unit, sentence): ~1000 VALU instructions per lane for a wave's 8 pairs) is shared out: wave w takes
+    // the (slice, sentence tile, unit pair) blocks w, w + KW, ... (round 2 left it to wave 0 alone while the other seven idled: ~2.5 us of a step).
+    auto cell_update = [&](int sl, int nt, int rq, float c, float gi, float gg, float gf, float go) {
         if (!live[nt]) return;
         const int b = b0 + 32 * nt + l31;
         const int u = 8 * (slice0 + sl) + 2 * rq + lh;
-        float c = cst[(size_t)u * Bp + b];
         c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
         cst[(size_t)u * Bp + b] = c;
         hout[nat_zidx(u, b, Bp)] = sigmoidf_(go) * tanhf(c);
     };
     if constexpr (KW == 1) {
 #pragma unroll
-        for (int sl = 0; sl < SL; ++sl)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq)
-                    cell_update(sl, nt, rq, acc[sl][nt][0][4 * rq + 0], acc[sl][nt][0][4 * rq + 1], acc[sl][nt][0][4 * rq + 2], acc[sl][nt][0][4 * rq + 3]);
-    } else {
-        if (kw == 0) {  // (it was the only reader of red[0] at the tree's last level, and nothing else writes it now)
-#pragma unroll
-            for (int sl = 0; sl < SL; ++sl)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[0][sl][nt][r][lane] = acc[sl][nt][0][r];
+        for (int blk = 0; blk < SL * NT * 4; ++blk) {
+            const int sl = blk / (NT * 4), nt = (blk / 4) % NT, rq = blk % 4;
+            cell_update(sl, nt, rq, cold[blk], acc[sl][nt][0][4 * rq + 0], acc[sl][nt][0][4 * rq + 1], acc[sl][nt][0][4 * rq + 2], acc[sl][nt][0][4 * rq + 3]);
         }
-        __syncthreads();
+    } else {
 #pragma unroll
         for (int blk = 0; blk < SL * NT * 4; ++blk) {
             if (blk % KW != kw) continue;  // wave-uniform
             const int sl = blk / (NT * 4), nt = (blk / 4) % NT, rq = blk % 4;
-            cell_update(sl, nt, rq, red[0][sl][nt][4 * rq + 0][lane], red[0][sl][nt][4 * rq + 1][lane], red[0][sl][nt][4 * rq + 2][lane],
-                        red[0][sl][nt][4 * rq + 3][lane]);
+            float gs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = red[0][sl][nt][4 * rq + i][lane];
+#pragma unroll
+                for (int w = 1; w < KW; ++w) v += red[w][sl][nt][4 * rq + i][lane];
+                gs[i] = v;
+            }
+            cell_update(sl, nt, rq, cold[blk / KW], gs[0], gs[1], gs[2], gs[3]);
         }
     }
 }
@@ -1033,7 +1025,8 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
 //     one wave per workgroup invalidates the caches (acquire fence) and the state is read with plain 16-byte loads.  Cache-wide RELEASE
 //     fences are what make a compiler-level grid sync cost 30+ us on this chip; this barrier measures 2-4 us
 //     (tools/kbench/grid_barrier.hip: modes 1 and 4).
-// Every sum is the per-frame kernels' sum in the same order: the mel is bit-identical to theirs (tools/experiments/r04/persist_check.py).  The
+// Every sum is the per-frame kernels' sum in the order they had when this was measured (commit 99b5d03: a tree over the K shares; they have since
+// moved to a one-barrier sum): the mel was bit-identical to theirs (tools/experiments/r04/persist_check.py at that commit).  The
 // spin is bounded: a barrier that is not met within ~seconds (a grid that is not resident: another resident kernel on the device) traps
 // instead of hanging.
 // **MEASURED, AND NOT SHIPPED (round 4): 26.7 ms for the acoustic model of 256 sentences against 22.4 with the per-frame launches.**  Per frame
@@ -1379,7 +1372,7 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_x3_k(NatLstmX3Ops ops, i
     typedef float f32x16 __attribute__((ext_vector_type(16)));
     using vtts::bf16x8;
     constexpr int PD = 3;
-    __shared__ float red[KW / 2][NT][16][64];
+    __shared__ float red[KW][NT][16][64];
     const int lane = threadIdx.x & 63, kw = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
     const int slice = blockIdx.x, b0 = blockIdx.y * 32 * NT;
     bool live[NT];
@@ -1414,6 +1407,14 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_x3_k(NatLstmX3Ops ops, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
     }
+    // this wave's cell-update block(s): the cell state is requested now, a kernel's length before it is needed
+    constexpr int NBLK = (NT * 4 + KW - 1) / KW;
+    float cold[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) {
+        const int blk = kw + q * KW, nt = blk / 4, rq = blk % 4;
+        cold[q] = blk < NT * 4 ? ops.cst[(size_t)(8 * slice + 2 * rq + lh) * Bp + b0 + 32 * nt + l31] : 0.0f;
+    }
     uint4 wv[PD][2], xv[PD][NT][2];
     const uint4* __restrict__ wsl = ops.wpk + (size_t)slice * NST * 2 * 64 + lane;
     auto load_st = [&](int st, int slot) {
@@ -1446,29 +1447,14 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_x3_k(NatLstmX3Ops ops, i
             load_st(nx < NW ? st_lo + nx : NST, j);
         }
     }
-    // fixed-order tree over the K shares, then the shared-out cell update (as in nat_dec_lstm_k)
-#pragma unroll
-    for (int half = KW / 2; half >= 1; half >>= 1) {
-        if (kw >= half && kw < 2 * half) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[kw - half][nt][r][lane] = acc[nt][r];
-        }
-        __syncthreads();
-        if (kw < half) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][r] += red[kw][nt][r][lane];
-        }
-        if (half > 1) __syncthreads();
-    }
-    if (kw == 0) {
+    // every wave leaves its share of the sums in LDS; after ONE barrier a wave adds the KW shares of its own cell-update block in wave order
+    // (round 4: a three-level tree with a barrier per level, and the cell state loaded only after it, cost 1.1 us of every step)
+    {
+        float* redf = &red[0][0][0][0];  // [KW][NT][16][64] (the kernel's LDS is sized for it under this switch)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[0][nt][r][lane] = acc[nt][r];
+            for (int r = 0; r < 16; ++r) redf[((kw * NT + nt) * 16 + r) * 64 + lane] = acc[nt][r];
     }
     __syncthreads();
 #pragma unroll
@@ -1476,9 +1462,20 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_x3_k(NatLstmX3Ops ops, i
         if (blk % KW != kw) continue;  // wave-uniform
         const int nt = blk / 4, rq = blk % 4;
         if (!live[nt]) continue;
-        const float gi = red[0][nt][4 * rq + 0][lane], gg = red[0][nt][4 * rq + 1][lane], gf = red[0][nt][4 * rq + 2][lane], go = red[0][nt][4 * rq + 3][lane];
+        float gs[4];
+        {
+            const float* redf = &red[0][0][0][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = redf[((0 * NT + nt) * 16 + 4 * rq + i) * 64 + lane];
+#pragma unroll
+                for (int w = 1; w < KW; ++w) v += redf[((w * NT + nt) * 16 + 4 * rq + i) * 64 + lane];
+                gs[i] = v;
+            }
+        }
+        const float gi = gs[0], gg = gs[1], gf = gs[2], go = gs[3];
         const int b = b0 + 32 * nt + l31, u = 8 * slice + 2 * rq + lh;
-        float c = ops.cst[(size_t)u * Bp + b];
+        float c = cold[blk / KW];
         c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
         ops.cst[(size_t)u * Bp + b] = c;
         const float hv = sigmoidf_(go) * tanhf(c);
