@@ -1651,6 +1651,14 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         any = any || f < nf[s];
     }
     if (!any) return;
+    // the projection's bias and the keep bytes of frame f + 1, requested before anything else (each was a cold load behind a barrier: 0.7 us of a step)
+    const float bb_h = g < MEL ? bp[g] : 0.0f;
+    unsigned char kp[2][4];
+#pragma unroll
+    for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            kp[which][s] = (keep && g < PN && b0 + s < B && f + 1 < Fmax) ? keep[(((size_t)(b0 + s) * Fmax + f + 1) * 2 + which) * PN + g] : (unsigned char)1;
 #pragma clang loop vectorize(disable)  // (it would pair the hi + lo additions of two rows into v_pk_add_f32: build.py)
     for (int k = g; k < 2 * H; k += 1024) {
         if constexpr (X3) {
@@ -1694,7 +1702,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     if (g < nchP * MEL) part[g] = partial(hs, wp, 2 * H, MEL, g % MEL, g / MEL, perP);
     __syncthreads();
     if (g < MEL) {
-        const float bb = bp[g];
+        const float bb = bb_h;
         const float4 a = gather(make_float4(bb, bb, bb, bb), MEL, g, nchP);
         prev[g] = a;
         const float v[4] = {a.x, a.y, a.z, a.w};
@@ -1709,7 +1717,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         if (keep) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                if (b0 + s < B) v[s] = keep[(((size_t)(b0 + s) * Fmax + f + 1) * 2 + which) * PN + col] ? v[s] * 2.0f : 0.0f;
+                if (b0 + s < B) v[s] = kp[which][s] ? v[s] * 2.0f : 0.0f;  // (col == g for both callers)
         }
         return make_float4(v[0], v[1], v[2], v[3]);
     };
