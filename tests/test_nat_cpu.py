@@ -142,6 +142,25 @@ def test_acoustic_oracle_properties():
     assert np.allclose(w.sum(axis=1), 1.0) and w.min() >= 0
 
 
+def test_gates_from_the_token_rows_identity():
+    """What csrc/nat.hip's gate path relies on (round 4): the conditioning only ever meets the first E rows of the LSTMs' input matrices, and
+    upsampling is linear, so  b + upsample(enc) @ W[0:E]  ==  b + upsample(enc @ W[0:E]) — the GEMM may run over the tokens' rows and the
+    upsampling weights mix its rows into the frames'.  Exact in exact arithmetic; in fp32 the two orders differ by rounding only."""
+    rng = np.random.default_rng(5)
+    L, E, G4 = 23, 64, 96
+    dur = np.abs(rng.normal(3.0, 1.5, size=L))
+    dur[7] = 0.0
+    nf = int(dur.sum())
+    W, b = rng.normal(size=(E, G4)) / np.sqrt(E), rng.normal(size=G4) * 0.1
+    enc = rng.normal(size=(L, E))
+    by_frames = no.gaussian_upsample(enc, dur, nf) @ W + b
+    by_tokens = no.gaussian_upsample(enc @ W, dur, nf) + b
+    assert by_frames.shape == (nf, G4) and np.abs(by_frames - by_tokens).max() < 1e-12
+    f32 = lambda a: a.astype(np.float32)
+    d32 = np.abs((no.gaussian_upsample(f32(enc), f32(dur), nf) @ f32(W) + f32(b)) - (no.gaussian_upsample(f32(enc) @ f32(W), f32(dur), nf) + f32(b))).max()
+    assert d32 < 2e-5, d32
+
+
 def test_threefry_known_answers():
     """Random123's kat_vectors for threefry2x32 with 20 rounds (the same three jax's own test suite uses) pin the cipher
     behind the device-drawn dropout masks."""
