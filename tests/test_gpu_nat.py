@@ -246,6 +246,42 @@ def test_integer_frame_counts_equal_the_reference_code_executed(tmp_path, monkey
     assert len(near) <= 2
 
 
+def test_pipeline_two_generator_passes_equal_one(model, acoustic, monkeypatch):
+    """A large job that fits one generator pass leaves in two (viettts_amd/pipeline.py::_generator_batches: the first pass's read-back runs
+    under the second's compute).  40 sentences with the frame threshold lowered so that the rule fires: the same samples, bit for bit, as
+    the single pass."""
+    from viettts_amd import pipeline
+    from viettts_amd.hifigan.config import V1
+    from viettts_amd.hifigan.generator import Generator
+    from viettts_amd.hifigan.synth import synthetic_params
+
+    dm, _, _ = model
+    am, _, _ = acoustic
+    rng = np.random.default_rng(43)
+    sents = [[FLAGS.sil_index] + list(rng.integers(4, 90, size=int(rng.integers(2, 12)))) + [FLAGS.sil_index] for _ in range(40)]
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    try:
+        one = pipeline.synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, gen_batch=1000)
+        calls = []
+        real = pipeline._generator_batches
+
+        def spy(*a, **k):
+            out = real(*a, **k)
+            calls.append(len(out))
+            return out
+
+        monkeypatch.setattr(pipeline, "SPLIT_MIN_FRAMES", 0)
+        monkeypatch.setattr(pipeline, "_generator_batches", spy)
+        two = pipeline.synthesize_sentences(sents, dm, am, gen, silence_duration=0.05)
+        assert calls == [2]
+        assert sorted(one) == sorted(two) == list(range(40))
+        for i in range(40):
+            assert np.array_equal(one[i], two[i]), i
+    finally:
+        gen.close()
+
+
 def test_pipeline_sharded_equals_unsharded(model, acoustic):
     """configs[3] on one GPU: 24 sentences through the batched pipeline; the union of two ranks' shards equals the
     single-rank result bit for bit (rows are independent at every stage; no exchange step)."""

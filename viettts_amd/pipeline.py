@@ -26,6 +26,10 @@ from .nat import text2mel as t2m
 PASS_FRAMES = 65536  # fallback for generators without the "pass_frames" option; mel frames per pass the generator's launches are sized for (engine.hip: pick_microbatch)
 
 
+SPLIT_MIN_FRAMES = 16384  # below this a second pass costs more than the read-back it hides
+TAIL_SHARE = 0.25  # measured 0.5 / 0.35 / 0.25: 52.7 / 53.0 / 52.3 ms (tools/experiments/r04/run29.sh)
+
+
 def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: int = 0, pass_frames: int = PASS_FRAMES) -> List[List[int]]:
     """Cut ``rows`` (sorted by ascending ``frames``) into the generator's ragged batches.  gen_batch > 0: at most that many sentences
     per batch.  gen_batch = 0: as few passes as PASS_FRAMES of REAL frames each allow (the ragged kernels skip the tiles past an
@@ -49,6 +53,18 @@ def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: in
             out.append([])
         out[-1].append(r)
         acc += int(f)
+    # A job that fits ONE pass still leaves in two when it is large: a pass's waveforms go to the host on a copy stream while the next pass
+    # computes, and the only pass's read-back (73 MB for the 256 transcript sentences) would be exposed in full.  The last pass — the longest
+    # sentences — takes TAIL_SHARE of the frames: its read-back is what stays exposed (256 sentences: 53.5 -> 52.3 ms).
+    if len(out) == 1 and len(rows) >= 32 and total >= SPLIT_MIN_FRAMES:
+        acc, cut = 0, len(rows) - 1
+        for i, f in enumerate(frames):
+            acc += int(f)
+            if acc >= total * (1.0 - TAIL_SHARE):
+                cut = i + 1
+                break
+        cut = min(max(cut, 1), len(rows) - 1)
+        out = [rows[:cut], rows[cut:]]
     return out
 
 
