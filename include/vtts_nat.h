@@ -161,6 +161,19 @@ int vtts_nat_acoustic_forward_groups(vtts_nat_acoustic* h, const int32_t* tokens
                                      int ngroups, const int32_t* group_row0, const int32_t* group_frames);
 /* Valid for the groups of the handle's LAST forward_groups() call (VTTS_ERR_STATE otherwise). */
 int vtts_nat_acoustic_wait_group(vtts_nat_acoustic* h, int group, void* stream);
+/*
+ * The token encoder alone, then the rest from its output (the text -> waveform pipeline: the encoder needs the tokens only, so it runs while
+ * the host still turns the duration model's seconds into frame counts).  enc_dev [B, Lmax, 2 * encoder_dim] fp32.  A row of it does not
+ * depend on its batch: rows may be re-ordered or dropped between the two calls (B and the row order of forward_from_encoder() are its own;
+ * Lmax must be encode()'s).  encode() needs workspace_bytes(h, B, Lmax, 1).  forward_from_encoder(ngroups = 0) gives forward()'s mel,
+ * ngroups >= 1 forward_groups()'s hand-over: the same mel, bit for bit.
+ */
+int vtts_nat_acoustic_encode(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, int B, int Lmax, float* enc_dev,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int vtts_nat_acoustic_forward_from_encoder(vtts_nat_acoustic* h, const float* enc_dev, const int32_t* lengths_dev, const float* durations_dev,
+                                           const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,
+                                           void* workspace, size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0,
+                                           const int32_t* group_frames);
 
 #ifdef __cplusplus
 }

@@ -516,6 +516,34 @@ def test_acoustic_bf16x3_option(acoustic, capsys):
         m.set_option("bf16x3", 2)
 
 
+def test_acoustic_from_a_precomputed_encoder_output(acoustic):
+    """vtts_nat_acoustic_encode + forward_from_encoder (AcousticModel.encode / ``encoded=``): the token encoder run ahead for a batch, its rows
+    re-ordered and a few dropped, then the rest of the model from them — the same mel, bit for bit, as the one-call forward of those sentences
+    (plain and with the grouped hand-over; a wider Lmax than the subset's own)."""
+    import torch
+
+    m, P, S = acoustic
+    cases = [_case(1300 + i, 2 + (i * 5) % 19) for i in range(37)]
+    enc = m.encode([c[0] for c in cases])
+    assert enc.shape == (37, max(len(c[0]) for c in cases), 512)
+    order = sorted((i for i in range(37) if i % 5 != 3), key=lambda i: (-cases[i][2], i))
+    sub = [cases[i] for i in order]
+    seeds = [9000 + i for i in order]
+    args = ([c[0] for c in sub], [c[1] for c in sub], [c[2] for c in sub])
+    rows = enc.index_select(0, torch.tensor(order, device=enc.device))
+    want = m(*args, dropout_seeds=seeds)
+    got = m(*args, dropout_seeds=seeds, encoded=rows)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    b = len(order)
+    grouped = m(*args, dropout_seeds=seeds, encoded=rows, to_host=False, group_row0=[0, b // 3, b])
+    torch.cuda.synchronize()
+    for i in (0, b // 2, b - 1):
+        assert np.array_equal(grouped[i, : sub[i][2]].cpu().numpy(), want[i]), i
+    with pytest.raises(ValueError):
+        m(*args, dropout_seeds=seeds, encoded=rows[:, :1])
+
+
 def test_nat_models_run_from_an_adopted_blob(model, acoustic):
     """The data-parallel start-up (viettts_amd.dist.setup_model_dp): a rank that never saw the checkpoint binds the
     packed blob rank 0 broadcast and computes the same durations and mel bit for bit."""

@@ -84,6 +84,8 @@ NAT_EXPORTS = (
     "vtts_nat_acoustic_forward",
     "vtts_nat_acoustic_forward_groups",
     "vtts_nat_acoustic_wait_group",
+    "vtts_nat_acoustic_encode",
+    "vtts_nat_acoustic_forward_from_encoder",
 )
 
 
@@ -220,6 +222,9 @@ def load(path=None) -> C.CDLL:
         "vtts_nat_acoustic_forward_groups": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.c_int,
                                                        C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         "vtts_nat_acoustic_wait_group": (C.c_int, [vp, C.c_int, vp]),
+        "vtts_nat_acoustic_encode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, sz, vp]),
+        "vtts_nat_acoustic_forward_from_encoder": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.c_int,
+                                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -2164,10 +2164,12 @@ VTTS_API int vtts_nat_debug_persist_clocks(unsigned long long* host_out) {  // [
 #endif
 #endif  // VTTS_NAT_PERSIST
 // forward() and forward_groups(): ngroups = 0 is the plain call (the postnet on the caller's stream after the last frame)
+// enc_pre: the token encoder's output [B][Lmax][2D] computed ahead by vtts_nat_acoustic_encode() (tokens_dev is not read then), or nullptr
 static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
                             const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev, void* workspace,
-                            size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0, const int32_t* group_frames) {
-    if (!h || !tokens_dev || !lengths_dev || !durations_dev || !nframes_dev || !mel_dev) return failf(VTTS_ERR_INVALID, "null argument");
+                            size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0, const int32_t* group_frames,
+                            const float* enc_pre = nullptr) {
+    if (!h || (!tokens_dev && !enc_pre) || !lengths_dev || !durations_dev || !nframes_dev || !mel_dev) return failf(VTTS_ERR_INVALID, "null argument");
     if (!h->blob) return failf(VTTS_ERR_STATE, "forward() before pack()/bind_packed()");
     size_t need = 0;
     int rc = vtts_nat_acoustic_workspace_bytes(h, B, Lmax, Fmax, &need);
@@ -2219,8 +2221,12 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
     float* G2 = take((size_t)B * Fmax * G4 * 4);
     float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);
     unsigned* ctl = reinterpret_cast<unsigned*>(take(4096));
-    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);  // model.py:131
-    if (rc) return rc;
+    if (enc_pre) {
+        enc = const_cast<float*>(enc_pre);  // read only from here on
+    } else {
+        rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc, s);  // model.py:131
+        if (rc) return rc;
+    }
     // :132 (upsample) lives inside the gates below: cond is never materialised (nat_gates_mix_k)
     HIP_TRYN(hipMemsetAsync(mel_dev, 0, (size_t)B * Fmax * MEL * 4, s));  // rows past a sentence's last frame
     // postnet (:113-121) + residual (:151) of rows [r0, r1) over their first `frames` frames: 4 x (Conv1D(PD, 5) + BatchNorm + tanh),
@@ -2411,6 +2417,44 @@ VTTS_API int vtts_nat_acoustic_forward_groups(vtts_nat_acoustic* h, const int32_
     if (ngroups < 1) return failf(VTTS_ERR_INVALID, "forward_groups() needs at least one group (got %d)", ngroups);
     return nat_acoustic_run(h, tokens_dev, lengths_dev, durations_dev, nframes_dev, B, Lmax, Fmax, keep_dev, mel_dev, workspace, workspace_bytes, stream,
                             ngroups, group_row0, group_frames);
+}
+
+// The token encoder alone, ahead of forward_from_encoder(): it needs the tokens only, so a pipeline can run it while the host still turns the
+// duration model's output into frame counts.  A row's output does not depend on its batch: rows may be re-ordered / dropped before
+// forward_from_encoder() (whose B and row order are its own; Lmax must be this call's).  Workspace: workspace_bytes(h, B, Lmax, 1) suffice.
+VTTS_API int vtts_nat_acoustic_encode(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, int B, int Lmax, float* enc_dev,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h || !tokens_dev || !lengths_dev || !enc_dev) return failf(VTTS_ERR_INVALID, "null argument");
+    if (!h->blob) return failf(VTTS_ERR_STATE, "encode() before pack()/bind_packed()");
+    size_t need = 0;
+    int rc = vtts_nat_acoustic_workspace_bytes(h, B, Lmax, 1, &need);
+    if (rc) return rc;
+    if (!workspace || workspace_bytes < need) return failf(VTTS_ERR_NOMEM, "workspace too small: %zu < %zu bytes", workspace_bytes, need);
+    const int D = h->cfg.encoder_dim, V = h->cfg.vocab_size;
+    char* p = static_cast<char*>(workspace);
+    auto take = [&](size_t bytes) {
+        float* r = reinterpret_cast<float*>(p);
+        p += align_up(bytes, 256);
+        return r;
+    };
+    float* bufA = take((size_t)B * Lmax * D * 4);
+    float* bufB = take((size_t)B * Lmax * D * 4);
+    float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);  // (fits: the full layout holds the same three buffers and more)
+    rc = run_token_encoder(*h, "token_encoder/~/", V, D, tokens_dev, lengths_dev, B, Lmax, bufA, bufB, lstm_ws, enc_dev, static_cast<hipStream_t>(stream));
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return failf(VTTS_ERR_HIP, "token encoder launch failed: %s", hipGetErrorString(e));
+    return VTTS_OK;
+}
+// forward() / forward_groups() (ngroups = 0: no hand-over) from an encoder output computed by vtts_nat_acoustic_encode(): the same mel, bit for bit
+VTTS_API int vtts_nat_acoustic_forward_from_encoder(vtts_nat_acoustic* h, const float* enc_dev, const int32_t* lengths_dev, const float* durations_dev,
+                                                    const int32_t* nframes_dev, int B, int Lmax, int Fmax, const uint8_t* keep_dev, float* mel_dev,
+                                                    void* workspace, size_t workspace_bytes, void* stream, int ngroups, const int32_t* group_row0,
+                                                    const int32_t* group_frames) {
+    if (!enc_dev) return failf(VTTS_ERR_INVALID, "null argument");
+    if (ngroups < 0) return failf(VTTS_ERR_INVALID, "ngroups must be >= 0 (got %d)", ngroups);
+    return nat_acoustic_run(h, nullptr, lengths_dev, durations_dev, nframes_dev, B, Lmax, Fmax, keep_dev, mel_dev, workspace, workspace_bytes, stream, ngroups,
+                            group_row0, group_frames, enc_dev);
 }
 
 VTTS_API int vtts_nat_acoustic_wait_group(vtts_nat_acoustic* h, int group, void* stream) {

@@ -56,7 +56,7 @@ class AcousticModel:
         if self.device.type != "cuda":
             raise ValueError("AcousticModel needs a ROCm device ('cuda:N'); there is no CPU path")
         self.cfg = _lib.NatAcousticCfg(vocab_size, encoder_dim, decoder_dim, prenet_dim, mel_dim, postnet_dim)
-        self.mel_dim, self.prenet_dim = mel_dim, prenet_dim
+        self.mel_dim, self.prenet_dim, self.encoder_dim = mel_dim, prenet_dim, encoder_dim
         self._h = C.c_void_p(0)
         dev_index = self.device.index if self.device.index is not None else 0
         _lib.check(self.lib, self.lib.vtts_nat_acoustic_create(C.byref(self.cfg), dev_index, C.byref(self._h)))
@@ -167,9 +167,36 @@ class AcousticModel:
         with torch.cuda.device(self.device):
             _lib.check(self.lib, self.lib.vtts_nat_acoustic_wait_group(self._h, int(group), C.c_void_p(st.cuda_stream)))
 
+    def encode(self, sentences: Sequence[Sequence[int]]) -> torch.Tensor:
+        """The token encoder alone (include/vtts_nat.h: vtts_nat_acoustic_encode), enqueued on the current stream: ``[B, Lmax, 2 * encoder_dim]`` on the
+        device.  It needs the tokens only — a pipeline runs it while the host still turns durations into frame counts — and a row does not depend
+        on its batch: select / re-order rows (``enc[rows]``) and hand them to :meth:`__call__` as ``encoded``."""
+        if self._blob is None:
+            raise RuntimeError("no parameters loaded")
+        B = len(sentences)
+        lens = [len(s) for s in sentences]
+        if B == 0 or min(lens) < 1:
+            raise ValueError("empty batch or token sequence")
+        Lmax = max(lens)
+        tok = np.zeros((B, Lmax), dtype=np.int32)
+        for i, s in enumerate(sentences):
+            tok[i, : lens[i]] = np.asarray(s, dtype=np.int32)
+        tok_d = torch.from_numpy(tok).to(self.device)
+        len_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
+        enc = torch.empty((B, Lmax, 2 * self.encoder_dim), dtype=torch.float32, device=self.device)
+        n = C.c_size_t(0)
+        _lib.check(self.lib, self.lib.vtts_nat_acoustic_workspace_bytes(self._h, B, Lmax, 1, C.byref(n)))
+        if self._ws is None or self._ws.numel() < n.value:
+            self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.vtts_nat_acoustic_encode(self._h, _ptr(tok_d), _ptr(len_d), B, Lmax, _ptr(enc), _ptr(self._ws), self._ws.numel(),
+                                                                   C.c_void_p(stream.cuda_stream)))
+        return enc
+
     def __call__(self, sentences: Sequence[Sequence[int]], durations_frames: Sequence[np.ndarray], n_frames: Sequence[int],
                  keep_masks: Optional[Sequence[np.ndarray]] = None, dropout_seeds: Optional[Sequence[int]] = None, to_host: bool = True,
-                 dropout_rng=None, group_row0: Optional[Sequence[int]] = None):
+                 dropout_rng=None, group_row0: Optional[Sequence[int]] = None, encoded: Optional[torch.Tensor] = None):
         """Per sentence: token ids, per-token durations in FRAMES, number of frames -> mel ``[n_frames, mel_dim]``.
         Dropout: explicit ``keep_masks`` (host arrays), or ``dropout_rng`` (the checkpoint's jax PRNGKey, uint32[2]: the
         reference's own mask stream, drawn on the GPU), or ``dropout_seeds`` (one int per sentence: this library's own
@@ -177,7 +204,9 @@ class AcousticModel:
         sentence's ``n_frames`` are zero) instead of per-sentence host arrays: the generator's input stays in HBM.
         ``group_row0`` (with ``to_host=False``): row boundaries ``[0, ..., B]`` of groups whose mel is handed over as soon as the decoder has
         produced the group's last frame (include/vtts_nat.h: vtts_nat_acoustic_forward_groups); a consumer stream waits for group g with
-        :meth:`wait_group`.  Same mel, bit for bit."""
+        :meth:`wait_group`.  Same mel, bit for bit.
+        ``encoded``: these sentences' rows of an :meth:`encode` output, in this call's order (``[B, L, 2 * encoder_dim]``, L >= the longest
+        sentence): the token encoder is skipped.  Same mel, bit for bit."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
         B = len(sentences)
@@ -185,6 +214,11 @@ class AcousticModel:
         if B == 0 or min(lens) < 1 or min(n_frames) < 1:
             raise ValueError("empty batch, token sequence or frame count")
         Lmax, Fmax = max(lens), int(max(n_frames))
+        if encoded is not None:
+            if encoded.dim() != 3 or encoded.shape[0] != B or encoded.shape[1] < Lmax or encoded.shape[2] != 2 * self.encoder_dim or encoded.dtype != torch.float32:
+                raise ValueError(f"encoded must be float32 [{B}, >= {Lmax}, {2 * self.encoder_dim}] (got {tuple(encoded.shape)} {encoded.dtype})")
+            encoded = encoded.contiguous()
+            Lmax = int(encoded.shape[1])
         tok = np.zeros((B, Lmax), dtype=np.int32)
         dur = np.zeros((B, Lmax), dtype=np.float32)
         for i, s in enumerate(sentences):
@@ -213,9 +247,19 @@ class AcousticModel:
             self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
-            if group_row0 is not None:
-                if to_host:
-                    raise ValueError("group_row0 hands the mel over on the device: use to_host=False")
+            if group_row0 is not None and to_host:
+                raise ValueError("group_row0 hands the mel over on the device: use to_host=False")
+            if encoded is not None:
+                r0 = [int(v) for v in group_row0] if group_row0 is not None else [0]
+                ng = len(r0) - 1
+                gfr = [max(int(n) for n in n_frames[r0[g] : r0[g + 1]]) if r0[g + 1] > r0[g] else 0 for g in range(ng)]
+                _lib.check(
+                    self.lib,
+                    self.lib.vtts_nat_acoustic_forward_from_encoder(self._h, _ptr(encoded), _ptr(len_d), _ptr(dur_d), _ptr(nf_d), B, Lmax, Fmax, _ptr(keep_d),
+                                                                    _ptr(out), _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream), ng,
+                                                                    (C.c_int32 * (ng + 1))(*r0), (C.c_int32 * max(ng, 1))(*(gfr or [0]))),
+                )
+            elif group_row0 is not None:
                 r0 = [int(v) for v in group_row0]
                 ng = len(r0) - 1
                 gfr = [max(int(n) for n in n_frames[r0[g] : r0[g + 1]]) if r0[g + 1] > r0[g] else 0 for g in range(ng)]

@@ -114,11 +114,20 @@ class DurationModel:
 
     def __call__(self, sentences: Sequence[Sequence[int]]) -> List[np.ndarray]:
         """Token-id lists -> per-sentence float32 arrays of seconds per token."""
+        if len(sentences) == 0:
+            return []
+        out, lens = self.launch(sentences)
+        host = out.cpu().numpy()
+        return [host[i, : lens[i]].copy() for i in range(len(lens))]
+
+    def launch(self, sentences: Sequence[Sequence[int]]):
+        """The same forward pass, enqueued on the current stream and NOT waited for: ``(seconds [B, Lmax] on the device, lengths)``.  A pipeline
+        records an event behind it, enqueues more work and reads the tensor back on a copy stream (viettts_amd/pipeline.py)."""
         if self._blob is None:
             raise RuntimeError("no parameters loaded")
         B = len(sentences)
         if B == 0:
-            return []
+            raise ValueError("empty batch")
         lens = [len(s) for s in sentences]
         if min(lens) < 1:
             raise ValueError("empty token sequence")
@@ -139,5 +148,4 @@ class DurationModel:
                 self.lib,
                 self.lib.vtts_nat_duration_forward(self._h, _ptr(tok_d), _ptr(len_d), B, Lmax, _ptr(out), _ptr(self._ws), self._ws.numel(), C.c_void_p(stream.cuda_stream)),
             )
-        host = out.cpu().numpy()
-        return [host[i, : lens[i]].copy() for i in range(B)]
+        return out, lens

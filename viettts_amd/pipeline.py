@@ -138,13 +138,38 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         torch.cuda.synchronize()
         t_last = time.perf_counter()
     toks = [list(token_lists[i]) for i in mine]
-    secs = duration_model(toks)  # [L] seconds per token each
-    t_last = mark("duration_s", t_last)
+    enc_all = None
+    if hasattr(duration_model, "launch") and hasattr(acoustic_model, "encode") and torch.cuda.is_available() and not os.environ.get("VTTS_PIPE_NO_EARLY_ENCODE"):
+        # The acoustic model's token encoder needs the tokens only: it is enqueued right behind the duration model and runs while the host reads the
+        # durations back (on the copy stream, behind an event) and turns them into frame counts — the GPU idled through that (~1 ms per 256 sentences).
+        # A row of the encoder's output does not depend on its batch (include/vtts_nat.h: vtts_nat_acoustic_encode): the rows are picked in the
+        # acoustic call's order below.
+        dev0 = getattr(acoustic_model, "device", None)
+        cur0 = torch.cuda.current_stream(dev0)
+        sec_dev, lens0 = duration_model.launch(toks)
+        ev_dur = torch.cuda.Event()
+        ev_dur.record(cur0)
+        enc_all = acoustic_model.encode(toks)
+        s_cp = _side_streams(torch.device(dev0) if not isinstance(dev0, torch.device) else dev0)[1]
+        s_cp.wait_event(ev_dur)
+        with torch.cuda.stream(s_cp):
+            sec_host = torch.empty(sec_dev.shape, dtype=sec_dev.dtype, pin_memory=True)
+            sec_host.copy_(sec_dev, non_blocking=True)
+            ev_host = torch.cuda.Event()
+            ev_host.record(s_cp)
+        sec_dev.record_stream(s_cp)
+        ev_host.synchronize()
+        hn = sec_host.numpy()
+        secs = [hn[i, : lens0[i]].copy() for i in range(len(lens0))]
+        t_last = mark("duration_s", t_last, sync=False)  # (the encoder is still running: its time shows up in acoustic_s)
+    else:
+        secs = duration_model(toks)  # [L] seconds per token each
+        t_last = mark("duration_s", t_last)
     frames, nfr, trail = t2m.frame_plan(toks, secs, silence_duration)  # text2mel.py:78-79, :90-102 for the whole shard at once
     # longest first: the decoder steps all sentences together and a 64-sentence tile leaves the per-frame launches once ITS longest
     # sentence is done, so tiles of similar lengths finish early (a sentence's mel does not depend on its row: rows are independent)
     ok = sorted((k for k, n in enumerate(nfr) if n >= 1), key=lambda k: (-nfr[k], k))
-    t_last = mark("host_rules_s", t_last)
+    t_last = mark("host_rules_s", t_last, sync=enc_all is None)
     wavs: Dict[int, np.ndarray] = {}
     gfr = {k: nfr[k] - trail[k] for k in ok}  # frames the generator sees: the mel minus its trailing silence (:102)
     if ok:
@@ -162,16 +187,21 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         # prenet dropout (on at inference, model.py:95-100): masks drawn on the GPU, seeded by the sentence's GLOBAL index.
         # The mel stays in HBM: [len(ok), Fmax, 80] on the device, rows past a sentence's frames zero.
         seeds = None if dropout_seed is None else [dropout_seed + mine[k] for k in ok]
+        enc_kw = {}
+        if enc_all is not None:
+            enc_kw["encoded"] = enc_all.index_select(0, torch.tensor(ok, dtype=torch.long, device=enc_all.device))  # a device-side gather (plumbing)
         if ngroups > 1:
             s_ac.wait_stream(cur)
+            if enc_kw:
+                enc_kw["encoded"].record_stream(s_ac)
             with torch.cuda.stream(s_ac):
                 mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False,
-                                         group_row0=bounds)
+                                         group_row0=bounds, **enc_kw)
                 ev_ac_end.record(s_ac)
             mel_dev.record_stream(cur)
             t_last = mark("acoustic_enqueue_s", t_last, sync=False)
         else:
-            mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False)
+            mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False, **enc_kw)
             t_last = mark("acoustic_s", t_last)
         # the generator takes ragged batches (vtts_hifigan_forward_ragged: each utterance's samples are those of running it
         # alone): a group's sentences sorted by length, cut into passes by _generator_batches, each cut to its longest
