@@ -521,6 +521,10 @@ def main():
                 # bf16 operands and 2460 on constant ones on this chip's power budget (profiles/r03_e_mfma_peak.txt, tools/kbench/coissue 400 3)
                 "peak_sustained_mfma_only_random_operands": 1750.0 if args.dtype == "bf16" else None,
                 "traffic_algorithmic": 2.0 * B * (T * 64) * 128 * 2 if prof["kernel"].startswith("resblock_pair_g_bf16_k<GTile<128, 11") else None,
+                # flat numeric keys (the driver's `parsed.roofline` keeps numbers): MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)
+                "mfma_util_dominant_kernel": util.get("dominant_kernel") if util else None,
+                "mfma_util_time_weighted_resblock_kernels": util.get("time_weighted_resblock_kernels") if util else None,
+                "lds_bank_conflict_cycles_dominant_kernel": util.get("lds_bank_conflict_cycles_dominant") if util else None,
                 "mfma_util": util,
                 "counters_unavailable": why_not,
                 "kernel": prof["kernel"],

@@ -127,11 +127,13 @@ int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, int T, fl
                          void* workspace, size_t workspace_bytes, vtts_stream stream);
 
 /*
- * forward() over utterances of DIFFERENT lengths in one batch (VTTS_BF16 handles): utterance b has frames_dev[b] mel
+ * forward() over utterances of DIFFERENT lengths in one batch (every dtype; VTTS_F32 / VTTS_BF16X3 since round 5: the sentence
+ * pipeline at the reference's 1e-4): utterance b has frames_dev[b] mel
  * frames (1 <= frames <= T) at the start of its [T, num_mels] slot.  Its first hop*frames[b] samples are exactly what
  * forward() returns for that utterance alone (B = 1, T = frames[b]) — every layer treats the rows past the utterance's
  * end as the reference's zero padding (model.py:8-10, "SAME") and skips the tiles beyond it — and the rest of its
- * [hop*T] slot is zero.  The reference has no batching at all (mel2wave.py:20-41 runs one utterance); this is the
+ * [hop*T] slot is zero.  (Bit for bit on VTTS_BF16 and VTTS_BF16X3; on VTTS_F32 for frame counts that are multiples of 4 — alone, another
+ * count routes ups_0 through the generic kernel, whose fmaf chain runs in another order: ~1e-7.)  The reference has no batching at all (mel2wave.py:20-41 runs one utterance); this is the
  * throughput form of running it once per sentence.
  *   frames_dev : [B] int32, device memory.  The counts are read on the device only (no host round trip); a value outside
  *                [0, T] is CLAMPED into it by every kernel, so a bad count can shorten or lengthen an utterance inside its
@@ -199,7 +201,8 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
  *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
  *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.
- *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read)
+ *   "profile"   1 = bracket the dominant kernel class with hipEvents (see profile_read); set "streams" = 1 with it — under the default two
+ *               streams a bracketed kernel shares the chip with the other micro-batch's and its duration is not its own
  * Read-only (get_option): "hop" (samples per mel frame), "max_frames_per_pass" (the SMALLEST T the engine refuses: forward() takes
  * T < max_frames_per_pass, an utterance of that many frames or more goes through the chunk scheduler), "pass_frames" (mel frames per call
  * the launches are sized for: schedulers that build batches aim at it), "graphs_cached".

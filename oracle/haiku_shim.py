@@ -10,7 +10,10 @@ the reference's source, executed, not a restatement; ``oracle/make_nat_golden.py
 What it does NOT buy: the primitives below (hk.LSTM, hk.Conv1D, hk.BatchNorm, hk.ResetCore, hk.dynamic_unroll,
 hk.deep_rnn_with_skip_connections, hk.dropout + the PRNG key chain, module naming) are this repo's reading of the
 third-party libraries (the same functions as oracle/nat_oracle.py, whose header lists the sources) — **unpinned by a JAX
-run**.  A wrong reading of a primitive is shared by shim and oracle and is not caught here.
+run**.  A wrong reading of a primitive is shared by shim and oracle and is not caught here; since round 5 the ARITHMETIC of each
+(LSTM step and sequence, BatchNorm in eval mode, tanh-gelu, softplus, SAME convolution, the upsampling softmax) is pinned against
+PyTorch's independent implementations (tests/test_nat_primitives_torch_cpu.py, 1e-12 in float64); Haiku's conventions (gate order,
+forget bias, layouts, module naming, the rng key chain) stay by reading.
 
 Module naming follows Haiku's rules: snake_case class name, numbered per creating scope (``lstm``, ``lstm_1``), joined
 with ``/~/`` when created inside the parent's ``__init__`` and ``/`` when created inside another method.

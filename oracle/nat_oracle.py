@@ -11,7 +11,13 @@ CPU (numpy) restatement of the INFERENCE side of the reference's NAT networks
   return.  ``duration_model`` below reproduces it bit for bit and ``acoustic_inference`` (with ``haiku_prenet_keep_masks``) to
   3e-15 (tests/test_nat_cpu.py): layer order, masks, the skip-connection order, the order of rng draws behind the always-on
   prenet dropout, text2mel's silence rules and frame arithmetic are the reference's.
-* **Unpinned by a JAX run**: the primitives themselves.  The reference's tests for these modules (tests/test_nat_duration.py,
+* **Primitives: arithmetic pinned against PyTorch's independent implementations (round 5), conventions by reading.**
+  ``tests/test_nat_primitives_torch_cpu.py`` compares ``lstm_step`` (one step and a whole sequence) with ``torch.nn.LSTMCell`` / ``nn.LSTM``
+  through the written-out gate permutation, ``batchnorm_eval`` with ``BatchNorm1d.eval()``, ``gelu_tanh`` with ``F.gelu(approximate="tanh")``,
+  ``softplus``, ``conv1d_same`` with ``F.conv1d`` (pads (k-1)//2, k//2; odd and even k) and ``gaussian_upsample`` with a torch softmax / einsum,
+  all to 1e-12 in float64 — so the arithmetic of each primitive is no longer a single reading shared with ``oracle/haiku_shim.py``.
+  What stays **unpinned by a JAX run** are Haiku's / JAX's CONVENTIONS listed below (gate order i, g, f, o and the +1 forget bias, weight layouts,
+  gelu's default form, SAME's pad split).  The reference's tests for these modules (tests/test_nat_duration.py,
   tests/test_nat_acoustic.py) assert output SHAPES only, ship no vector, and need jax + dm-haiku, which cannot be installed here
   (SURVEY.md §4, Appendix D); no NAT checkpoint ships with the reference either.  The shim's primitives ARE the functions below, so
   a wrong reading of one of them is shared and not caught.  What is restated is the published behaviour of the third-party modules

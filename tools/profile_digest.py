@@ -89,7 +89,12 @@ def main():
             "avg_us_timed": st["avg_us_timed"] if st else None,
             "timed_calls": st["timed_calls"] if st else None,
         }
-    rb = {k: v for k, v in kern.items() if (k.startswith("resblock_") or k.startswith("conv1d_f32_mfma_k")) and v["mfma_util"] is not None and v["avg_us_timed"]}
+    def is_resblock_kernel(k):
+        if dt == "bf16x3":  # the split engine's own ResBlock kernels only (round 4 averaged the fp32 side leg's kernels in: VERDICT r04)
+            return k.startswith("resblock_") and "x3" in k
+        return k.startswith("resblock_") or (k.startswith("conv1d_f32_mfma_k") and "ConvTile<80" not in k)  # (conv_pre is no ResBlock convolution)
+
+    rb = {k: v for k, v in kern.items() if is_resblock_kernel(k) and v["mfma_util"] is not None and v["avg_us_timed"]}
     tw = (sum(v["mfma_util"] * v["avg_us_timed"] * v["timed_calls"] for v in rb.values()) /
           sum(v["avg_us_timed"] * v["timed_calls"] for v in rb.values())) if rb else None
     with open(os.path.join(run, f"{tag}{sfx}_pmc.md"), "w") as f:

@@ -28,7 +28,7 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCL
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_f32/p2 -- $BENCH32 > $O/pmc_f32_p2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_f32/p3 -- $BENCH32 > $O/pmc_f32_p3.log 2>&1
 # the split-operand engine (VTTS_BF16X3) at the same shape, same schedule
-BENCHX3="python $R/bench.py --dtype bf16x3 --streams 1 --microbatch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-rtf"
+BENCHX3="python $R/bench.py --dtype bf16x3 --streams 1 --microbatch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-rtf --no-f32"  # --no-f32: without it the fp32 side leg ran inside this trace and its 0.85-MfmaUtil kernels were averaged into the x3 figure (round 4: 0.691 committed, 0.50 true)
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_bf16x3 -o r -- $BENCHX3 > $O/trace_bf16x3.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_bf16x3/p1 -- $BENCHX3 > $O/pmc_bf16x3_p1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_bf16x3/p2 -- $BENCHX3 > $O/pmc_bf16x3_p2.log 2>&1

@@ -110,7 +110,7 @@ struct vtts_hifigan {
     int cur_T = 0;                  // ... of the T allocated
     int64_t opt_tiles = 0;           // 0 auto, 1 wide, 2 narrow
     int64_t opt_fuse = 2;            // bf16: 0 one kernel per convolution, 1 fused pairs, 2 fused pairs + whole ResBlocks at C = 32
-    int64_t opt_streams = 0;         // micro-batches in flight on separate HIP streams (1..4; 0 = by engine: fp32 2, bf16 1 — auto_streams)
+    int64_t opt_streams = 0;         // micro-batches in flight on separate HIP streams (1..4; 0 = the engines' default: 2 — auto_streams)
     int64_t opt_graph = 1;           // small launches: replay a captured hipGraph once the same buffers were seen twice (0 = always eager)
     struct GraphEntry {
         const void* mel = nullptr;
@@ -381,6 +381,13 @@ struct Act {  // channel-major activation view
 // gpurun_out/r03_exp40; the fp32 MFMA kernels take the same flag).  The samples do not depend on the order: utterances are independent.
 int next_zrev(vtts_hifigan* h) { return h->opt_zigzag ? (int)(h->zrev_count++ & 1) : 0; }
 
+// ragged batches on the fp32 / bf16x3 engines (vtts_hifigan_forward_ragged): a layer whose input has L columns per utterance slot learns each
+// utterance's valid columns = frames * (columns per frame) (device_common.h: valid_len)
+void set_ragged(const vtts_hifigan* h, ConvArgs& a, int L) {
+    a.lens = h->cur_lens ? h->cur_lens + h->cur_b0 : nullptr;
+    a.len_mul = h->cur_lens ? L / h->cur_T : 1;
+}
+
 int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_in, const float* res, float* y,
               int acc_mode, float div, int tanh_out, float* pre_act, hipStream_t s) {
     ConvArgs a;
@@ -411,6 +418,7 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
     a.pre_act = pre_act;
     a.tile_pref = (int)h->opt_tiles;
     a.zrev = next_zrev(h);
+    set_ragged(h, a, L);
 
     hipError_t e;
     const bool ncw = x.st == 1 && x.sc == L && (x.sb % 4) == 0;
@@ -493,7 +501,23 @@ int run_pair_f32(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float*
     a.acc_mode = acc_mode;
     a.div = div;
     a.zrev = next_zrev(h);
+    set_ragged(h, a, L);
+    const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;  // (fuse = 3: the dominant class runs here)
+    if (prof) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            h->prof_events.emplace_back(e0, e1);
+        }
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+    }
     hipError_t e = launch_pair_f32(a, h->blob + c2.off_wp, reinterpret_cast<const float*>(h->blob + c2.off_b), s);
+    if (prof) {
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+        h->prof_used++;
+        h->prof_flops += 2.0 * 2.0 * (double)B * L * c1.cin * c1.cout * c1.k;  // two convolutions
+    }
     if (e != hipSuccess) return fail(VTTS_ERR_HIP, "fused fp32 pair launch for %s failed: %s", c1.key.c_str(), hipGetErrorString(e));
     return VTTS_OK;
 }
@@ -527,6 +551,7 @@ int run_pair_x3(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float* 
     a.acc_mode = acc_mode;
     a.div = div;
     a.zrev = next_zrev(h);
+    set_ragged(h, a, L);
     const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
     if (prof) {
         if (h->prof_used == h->prof_events.size()) {
@@ -1006,6 +1031,7 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
         float* bufS = reinterpret_cast<float*>(wsb + 3 * per);   // MRF accumulator xs / stage output
         if (par) bufS = reinterpret_cast<float*>(wsb + 1 * per);  // parallel ResBlocks: [X | S | (T, C, Y) per ResBlock] (one micro-batch, si == 0)
         const int nb = std::min(mb, B - b0);
+        h->cur_b0 = b0;
         int rc;
         // conv_pre (model.py:110): mel [nb][T][num_mels] NWC -> S [nb][C0][T]
         {
@@ -1444,7 +1470,6 @@ VTTS_API int vtts_hifigan_forward(vtts_hifigan* h, const float* mel_dev, int B, 
 VTTS_API int vtts_hifigan_forward_ragged(vtts_hifigan* h, const float* mel_dev, const int32_t* frames_dev, int B, int T, float* wav_dev,
                                          void* workspace, size_t workspace_bytes, vtts_stream stream) {
     if (!h || !mel_dev || !frames_dev || !wav_dev) return fail(VTTS_ERR_INVALID, "null argument");
-    if (h->dtype != VTTS_BF16) return fail(VTTS_ERR_INVALID, "ragged batches run on the bf16 engine (the fp32 engine takes equal-length batches)");
     if (B <= 0 || T <= 0) return fail(VTTS_ERR_INVALID, "B and T must be positive (got B=%d, T=%d)", B, T);
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(wav_dev, 0, (size_t)B * h->hop * T * sizeof(float), s));  // samples past an utterance's end
@@ -1582,9 +1607,12 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
 
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
-    {  // setting an option to the value it has changes nothing: captured graphs stay valid
-        int64_t cur = 0;
-        if (strcmp(name, "profile") && vtts_hifigan_get_option(h, name, &cur) == VTTS_OK && cur == value) return VTTS_OK;
+    {  // setting a WRITABLE option to the value it has changes nothing: captured graphs stay valid (read-only and unknown names fall through to their errors)
+        static const char* const writable[] = {"kernels", "microbatch", "fuse", "streams", "graph", "zigzag", "chains", "tiles"};
+        for (const char* w : writable) {
+            int64_t cur = 0;
+            if (!strcmp(name, w) && vtts_hifigan_get_option(h, name, &cur) == VTTS_OK && cur == value) return VTTS_OK;
+        }
     }
     ++h->epoch;  // a captured launch sequence reflects the options it was captured under
     if (!strcmp(name, "kernels")) {
@@ -1613,6 +1641,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
         h->opt_tiles = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
+    } else if (!strcmp(name, "hop") || !strcmp(name, "pass_frames") || !strcmp(name, "max_frames_per_pass") || !strcmp(name, "graphs_cached") ||
+               !strcmp(name, "profile_C") || !strcmp(name, "profile_K")) {
+        return fail(VTTS_ERR_INVALID, "option '%s' is read-only", name);
     } else {
         return fail(VTTS_ERR_INVALID, "unknown option '%s'", name);
     }

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    const int L = a.L;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int LP = a.L;              // row pitch of x / res / y
+    const int L = valid_len(a, b);   // this utterance's columns (ragged batches; == LP otherwise)
     // XCD-aware tile order (as the bf16 pair kernel, kernels_bf16_rbg.hip): workgroups go to the 8 XCDs round-robin in launch order, so on
     // launches of at least F32_XCD_MIN_TILES tiles per row of the grid (gridDim.x then padded to a multiple of 8 by the launcher) XCD
     // blockIdx.x % 8 takes a contiguous, balanced eighth of the time tiles: a tile's halo columns were staged by the same L2's previous tile
@@ -88,8 +90,8 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
         if (tile >= hi) return;
     }
     const int t0 = tile * NT;
+    if (t0 >= L) return;  // a tile past the utterance's end (ragged batches)
     const int m0 = blockIdx.y * MT + wm * (MT / T::WM);  // first output channel of this wave
-    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const float slope = a.slope_in;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
 
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
                 const int c4 = idx - row * W4;
                 const int t = t0 - PA + 4 * c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + t);
+                if (t >= 0 && t < L) v = mask_tail4(*reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + t), t, L);
                 v.x = lrelu(v.x, slope);
                 v.y = lrelu(v.y, slope);
                 v.z = lrelu(v.z, slope);
@@ -209,21 +211,21 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        a.y[((long)b * COUT + co) * L + t] = acc[mr][nr][r] + a.bias[co];
+                        a.y[((long)b * COUT + co) * LP + t] = acc[mr][nr][r] + a.bias[co];
                     }
                 }
                 continue;
             }
             // 8 values per round trip, 32-bit element offsets inside the utterance (COUT * L < 2^31): the register budget of three workgroups per CU
-            const float* __restrict__ resb = has_res ? a.res + (long)b * COUT * L : a.y + (long)b * COUT * L;
-            float* yb = a.y + (long)b * COUT * L;
+            const float* resb = has_res ? a.res + (long)b * COUT * LP : a.y + (long)b * COUT * LP;  // no __restrict__: the un-fused ResBlock path runs in place (res == y)
+            float* yb = a.y + (long)b * COUT * LP;
 #pragma unroll
             for (int r0 = 0; r0 < 16; r0 += 8) {
                 float rv[8], yv[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
-                    const int off = (m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc;
+                    const int off = (m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tc;
                     rv[q] = has_res ? resb[off] : 0.0f;
                     yv[q] = mode != ACC_STORE ? yb[off] : 0.0f;
                 }
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256, 3) void conv1d_f32_mfma_k(ConvArgs a) {  // re
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const int off = co * L + tc;
+                    const int off = co * LP + tc;
                     float v = acc[mr][nr][r] + a.bias[co];
                     if (has_res) v = v + rv[q];
                     if (mode == ACC_ADD) v = yv[q] + v;
@@ -384,7 +386,9 @@ __global__ __launch_bounds__(256) void convT1d_f32_mfma_k(ConvArgs a) {
     const int q0 = blockIdx.x * NT;
     const int m0 = blockIdx.y * MT + wm * (MT / T::WM);
     const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
-    const int L = a.L;
+    const int LP = a.L;              // row pitch of x (frames); y's is LP * S
+    const int L = valid_len(a, b);   // this utterance's input frames (ragged batches; == LP otherwise)
+    if (q0 >= L) return;
     const float slope = a.slope_in;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
 
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(256) void convT1d_f32_mfma_k(ConvArgs a) {
                 const int c4 = idx - row * W4;
                 const int t = q0 - PA + 4 * c4;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t >= 0 && t < L) v = *reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + t);
+                if (t >= 0 && t < L) v = mask_tail4(*reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + t), t, L);  // a ragged utterance's frame count need not be a multiple of 4
                 v.x = lrelu(v.x, slope);
                 v.y = lrelu(v.y, slope);
                 v.z = lrelu(v.z, slope);
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256) void convT1d_f32_mfma_k(ConvArgs a) {
     }
 
     // ---- epilogue: lane owns S consecutive samples y[co][S*q .. S*q + S-1] per (co) it holds ----
-    const long Lout = (long)L * S;
+    const long Lout = (long)LP * S;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
 #pragma unroll
@@ -589,7 +593,8 @@ __global__ __launch_bounds__(256) void conv_post_k(ConvArgs a) {
     for (int i = threadIdx.x; i < KS * C; i += 256) ws[i] = a.w[i];  // Haiku [K][Cin][1]
     __syncthreads();
     const int b = blockIdx.y;
-    const long L = a.L;
+    const long LP = a.L;             // row pitch
+    const long L = valid_len(a, b);  // this utterance's samples (ragged batches; == LP otherwise): the rest of its wav slot stays as the caller left it
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
     const float slope = a.slope_in;
     const float bias = a.bias[0];
@@ -601,8 +606,8 @@ __global__ __launch_bounds__(256) void conv_post_k(ConvArgs a) {
             float v[12];
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 lo = (t >= 4) ? *reinterpret_cast<const float4*>(xr - 4) : z;
-            const float4 mid = *reinterpret_cast<const float4*>(xr);
-            const float4 hi = (t + 4 < L) ? *reinterpret_cast<const float4*>(xr + 4) : z;
+            const float4 mid = mask_tail4(*reinterpret_cast<const float4*>(xr), (int)t, (int)L);
+            const float4 hi = (t + 4 < L) ? mask_tail4(*reinterpret_cast<const float4*>(xr + 4), (int)t + 4, (int)L) : z;
             v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
             v[4] = mid.x; v[5] = mid.y; v[6] = mid.z; v[7] = mid.w;
             v[8] = hi.x; v[9] = hi.y; v[10] = hi.z; v[11] = hi.w;
@@ -618,9 +623,17 @@ __global__ __launch_bounds__(256) void conv_post_k(ConvArgs a) {
         float4 pre, out;
         pre.x = acc[0] + bias; pre.y = acc[1] + bias; pre.z = acc[2] + bias; pre.w = acc[3] + bias;
         out.x = tanhf(pre.x); out.y = tanhf(pre.y); out.z = tanhf(pre.z); out.w = tanhf(pre.w);
-        const long idx = (long)b * L + t;
-        if (a.pre_act) *reinterpret_cast<float4*>(a.pre_act + idx) = pre;
-        *reinterpret_cast<float4*>(a.y + idx) = out;
+        const long idx = (long)b * LP + t;
+        if (t + 4 <= L) {
+            if (a.pre_act) *reinterpret_cast<float4*>(a.pre_act + idx) = pre;
+            *reinterpret_cast<float4*>(a.y + idx) = out;
+        } else {  // (a valid length that is not a multiple of 4: no V1 layer has one — hop = 256 — but a bad count must not leave the slot's rules)
+            const float pv[4] = {pre.x, pre.y, pre.z, pre.w}, ov[4] = {out.x, out.y, out.z, out.w};
+            for (int e = 0; e < 4 && t + e < L; ++e) {
+                if (a.pre_act) a.pre_act[idx + e] = pv[e];
+                a.y[idx + e] = ov[e];
+            }
+        }
     }
 }
 

@@ -76,8 +76,10 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
     const int l31 = lane & 31;
     const int lh = lane >> 5;
 
-    const int L = a.L;
-    // XCD-aware tile order (as conv1d_f32_mfma_k): XCD blockIdx.x % 8 takes a contiguous, balanced eighth of the time tiles
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int LP = a.L;              // row pitch of x / y
+    const int L = valid_len(a, b);   // this utterance's columns (ragged batches; == LP otherwise): zero padding and store masks follow it
+    // XCD-aware tile order (as conv1d_f32_mfma_k): XCD blockIdx.x % 8 takes a contiguous, balanced eighth of the utterance's time tiles
     int tile = blockIdx.x;
     if (gridDim.x >= FP_XCD_MIN_TILES) {
         const int nt = (L + NT2 - 1) / NT2, r = (int)((blockIdx.x + blockIdx.z) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
@@ -86,7 +88,6 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
     }
     const int t0 = tile * NT2;  // first output time of this workgroup
     if (t0 >= L) return;
-    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int dil = a.dil;
     const int h1 = H2 * dil;                     // c1's symmetric pad (model.py:8-10)
     const int tstart = t0 - H2 - h1;             // time of X column `off`: c1's output column n, tap j reads time tstart + n + j*dil
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 const int c4 = idc - row * w4;
                 const int t = tx0 + 4 * c4;
                 const bool ok = idx < total && t >= 0 && t < L;
-                const int tc = t < 0 ? 0 : (t >= L ? L - 4 : t);
-                v[i] = *reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + tc);
+                const int tc = t < 0 ? 0 : (t >= LP ? LP - 4 : t);
+                v[i] = mask_tail4(*reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + tc), t, L);
                 if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 dst[i] = idx < total ? row * rsx + 4 * c4 : -1;
             }
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 for (int q = 0; q < EB; ++q) {
                     const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const long idx = ((long)b * C + co) * L + tc;
+                    const long idx = ((long)b * C + co) * LP + tc;
                     rv[q] = a.res[idx];
                     yv[q] = mode != ACC_STORE ? a.y[idx] : 0.0f;
                 }
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 for (int q = 0; q < EB; ++q) {
                     const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const long idx = ((long)b * C + co) * L + tc;
+                    const long idx = ((long)b * C + co) * LP + tc;
                     float v = acc[mr][nr][r] + p.bias2[co];
                     v = v + rv[q];
                     if (mode == ACC_ADD) v = yv[q] + v;

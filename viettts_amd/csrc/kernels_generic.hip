@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void conv1d_generic_k(ConvArgs a) {
     const int co0 = blockIdx.y * COT;
     const int b = blockIdx.z;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
+    const int Lv = valid_len(a, b);  // ragged batches: this utterance's columns (a.L = a.Lout stay the row pitch)
 
     float acc[COT];
 #pragma unroll
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void conv1d_generic_k(ConvArgs a) {
 
     for (int j = 0; j < a.K; ++j) {
         const int ti = t + j * a.dil - a.pad;
-        const bool ok = (t < a.Lout) && (ti >= 0) && (ti < a.L);
+        const bool ok = (t < Lv) && (ti >= 0) && (ti < Lv);
         const float* xp = xb + (long)ti * a.x_st;
         const float* wj = a.w + (long)j * a.Cin * a.Cout + co0;
         for (int ci = 0; ci < a.Cin; ++ci) {
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void conv1d_generic_k(ConvArgs a) {
             }
         }
     }
-    if (t >= a.Lout) return;
+    if (t >= Lv) return;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
         const int co = co0 + c;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void convT1d_generic_k(ConvArgs a) {
     const int co0 = (blockIdx.y / s) * COT;
     const int b = blockIdx.z;
     const float* __restrict__ xb = a.x + (long)b * a.x_sb;
+    const int Lv = valid_len(a, b);  // ragged batches: this utterance's input frames
 
     float acc[COT];
 #pragma unroll
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void convT1d_generic_k(ConvArgs a) {
     if (j0 < 0) j0 += s;
     for (int j = j0; j < a.K; j += s) {
         const int ti = q + (r + j - a.pad_a) / s;  // exact: r + j - pad_a is a multiple of s
-        const bool ok = (q < a.L) && (ti >= 0) && (ti < a.L);
+        const bool ok = (q < Lv) && (ti >= 0) && (ti < Lv);
         const float* xp = xb + (long)ti * a.x_st;
         const float* wj = a.w + ((long)j * a.Cout + co0) * a.Cin;  // [K][Cout][Cin]
         for (int ci = 0; ci < a.Cin; ++ci) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void convT1d_generic_k(ConvArgs a) {
             }
         }
     }
-    if (q >= a.L) return;
+    if (q >= Lv) return;
     const int p = q * s + r;
 #pragma unroll
     for (int c = 0; c < COT; ++c) {

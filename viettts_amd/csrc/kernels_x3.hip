@@ -76,7 +76,9 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lh = lane >> 5;
-    const int L = a.L;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int LP = a.L;              // row pitch of x / y
+    const int L = valid_len(a, b);   // this utterance's columns (ragged batches; == LP otherwise): zero padding and store masks follow it
     int tile = blockIdx.x;
     if (gridDim.x >= X3_XCD_MIN_TILES) {  // XCD-aware tile order (as the other pair kernels): XCD blockIdx.x % 8 takes a contiguous eighth of the tiles
         const int nt = (L + NT2 - 1) / NT2, r = (int)((blockIdx.x + blockIdx.z) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
@@ -85,10 +87,9 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
     }
     const int t0 = tile * NT2;
     if (t0 >= L) return;
-    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int h1 = H2 * dil;
     const int rowsx = N1 + 2 * h1;           // X rows: times t0 - H2 - h1 ...
-    const float* __restrict__ xb = a.x + (long)b * C * L;
+    const float* __restrict__ xb = a.x + (long)b * C * LP;
     const int m0 = wm * (C / T::WM);         // first output channel of this wave
     const float slope = a.slope_in;
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
         const int tx0 = t0 - H2 - h1;
         const int nblk = (rowsx + 63) >> 6;
         const int units = nblk * SPR1;  // (64-row block, 16-byte slot)
-        const float* __restrict__ xc0 = xb + (long)(xc * XC) * L;
+        const float* __restrict__ xc0 = xb + (long)(xc * XC) * LP;
         constexpr int UB = 4;           // units in flight per thread: 32 dword loads
         for (int u0 = wave * UB; u0 < units; u0 += NWAVES * UB) {
             float v[UB][8];
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
                 const int t = tx0 + row[q];
                 const bool ok = live[q] && row[q] < rowsx && t >= 0 && t < L;
                 const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-                const float* __restrict__ g = xc0 + (long)(slot[q] * 8) * L + tc;  // unconditional loads from clamped addresses, masked afterwards
+                const float* __restrict__ g = xc0 + (long)(slot[q] * 8) * LP + tc;  // unconditional loads from clamped addresses, masked afterwards
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * L];
+                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * LP];
                 if (!ok) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] = 0.0f;
@@ -298,8 +299,8 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
     // of the c2 loop they would arrive for free, but 64 more live registers spill: 94 VGPRs, measured by the compiler.)
     const int mode = a.acc_mode;
     const float dv = a.div;
-    const float* __restrict__ resb = a.res + (long)b * C * L;
-    float* yb = a.y + (long)b * C * L;
+    const float* __restrict__ resb = a.res + (long)b * C * LP;
+    float* yb = a.y + (long)b * C * LP;
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr) {
         float rres[NR][16];  // one m-block's residual values per round trip (all MR * NR * 16 at once spill)
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
             const int t = t0 + n;
             const int tc = (n < NT2 && t < L) ? t : 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) rres[nr][r] = resb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc];
+            for (int r = 0; r < 16; ++r) rres[nr][r] = resb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tc];
         }
 #pragma unroll
         for (int nr = 0; nr < NR; ++nr) {
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
-                    yv[q] = mode != ACC_STORE ? yb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * L + tc] : 0.0f;
+                    yv[q] = mode != ACC_STORE ? yb[(m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tc] : 0.0f;
                 }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
                     v = v + rres[nr][r];
                     if (mode == ACC_ADD) v = yv[q] + v;
                     else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;
-                    if (ok) yb[co * L + tc] = v;
+                    if (ok) yb[co * LP + tc] = v;
                 }
             }
         }
@@ -463,12 +464,13 @@ __global__ __launch_bounds__(T::THREADS, 2) void convt_x3_k(ConvArgs a) {
     unsigned char* const tlo = lds + T::PLANE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, lh = lane >> 5;
-    const int L = a.L, Lout = a.Lout;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int LP = a.L, Lout = a.Lout;  // row pitches of x and y
+    const int L = valid_len(a, b);      // this utterance's input frames (ragged batches; == LP otherwise)
     const int t0 = blockIdx.x * N1;  // first input frame of this workgroup
     if (t0 >= L) return;
-    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
     const int mblk = blockIdx.y * T::WM + wm;  // this wave's 32-row block of m' (in both groups)
-    const float* __restrict__ xb = a.x + (long)b * CIN * L;
+    const float* __restrict__ xb = a.x + (long)b * CIN * LP;
     const float slope = a.slope_in;
     auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
         hi = pack_bf16x2(v0, v1);
@@ -490,9 +492,9 @@ __global__ __launch_bounds__(T::THREADS, 2) void convt_x3_k(ConvArgs a) {
                 const int t = t0 - 1 + row[q];
                 const bool ok = live[q] && row[q] < ROWS && t >= 0 && t < L;
                 const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
-                const float* __restrict__ g = xb + (long)(slot[q] * 8) * L + tc;
+                const float* __restrict__ g = xb + (long)(slot[q] * 8) * LP + tc;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * L];
+                for (int e = 0; e < 8; ++e) v[q][e] = g[(long)e * LP];
                 if (!ok) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[q][e] = 0.0f;

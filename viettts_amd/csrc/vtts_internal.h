@@ -56,6 +56,11 @@ struct ConvArgs {
     float* pre_act;      // optional copy of the pre-tanh value (same indexing as y) or nullptr
     int tile_pref;       // MFMA time-tile choice: 0 = by problem size, 1 = wide, 2 = narrow (tests)
     int zrev;            // MFMA kernels: 1 = utterance = gridDim.z - 1 - blockIdx.z (engine.hip: next_zrev)
+    // ragged batch (vtts_hifigan_forward_ragged on the fp32 / bf16x3 engines): utterance b's valid INPUT length is lens[b] * len_mul of the L
+    // allocated (L stays the row pitch); everything past it reads as the reference's zero padding (model.py:8-10, lax "SAME"), nothing past
+    // it is stored, tiles past it exit at once.  nullptr = all L columns valid.  device_common.h: valid_len
+    const int* lens;     // [B] mel frames per utterance (device memory)
+    int len_mul;         // input columns of this layer per mel frame
 };
 
 // ---- generic (any shape) fp32 kernels: kernels_generic.hip -------------------------------

@@ -175,9 +175,11 @@ class Generator:
         return out
 
     def forward_ragged(self, mel: torch.Tensor, frames, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Utterances of different lengths in one batch (bf16 engine): ``mel`` ``[B, Tmax, num_mels]`` with utterance b's
+        """Utterances of different lengths in one batch (every engine): ``mel`` ``[B, Tmax, num_mels]`` with utterance b's
         ``frames[b]`` frames at the start of its slot.  ``out[b, :hop*frames[b]]`` equals ``self(mel[b:b+1, :frames[b]])``
-        bit for bit; the rest of the row is zero.  ``frames``: int sequence or int32 tensor on the device."""
+        bit for bit (fp32 engine: for frame counts that are multiples of 4 — an utterance run alone with another count takes the generic
+        first transposed convolution, whose sums run in another order: ~1e-7); the rest of the row is zero.  ``frames``: int sequence or
+        int32 tensor on the device."""
         mel = self._check_mel(mel)
         B, T, _ = mel.shape
         if isinstance(frames, torch.Tensor):

@@ -6,8 +6,9 @@ Sentences are independent at every step, so a corpus shards with no exchange ste
 and keeps its waveforms.  The only collectives of the whole job are the three start-up weight broadcasts
 (viettts_amd/dist.py).  Within a rank the stages run batched:
     tokens --DurationModel--> seconds/token --rules (text2mel.py:90-97)--> frames --AcousticModel--> mel --Generator--> wav
-with the generator fed ragged batches (sentences sorted by length, each batch padded to its longest; the bf16 engine
-gives every utterance the zero padding it would see alone and skips the tiles past its end); optionally the last two stages
+with the generator fed ragged batches (sentences sorted by length, each batch padded to its longest; every engine — bf16, and since
+round 5 fp32 and bf16x3, the ones that answer to the reference's 1e-4 — gives every utterance the zero padding it would see alone and
+skips the tiles past its end); optionally the last two stages
 overlap: the acoustic model hands its mel over in groups as the decoder finishes them (synthesize_sentences, overlap_groups).
 """
 from __future__ import annotations
@@ -174,7 +175,7 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     gfr = {k: nfr[k] - trail[k] for k in ok}  # frames the generator sees: the mel minus its trailing silence (:102)
     if ok:
         dev = generator.device
-        ragged = getattr(generator, "dtype_name", "") == "bf16"  # the fp32 engine takes one utterance (length) at a time
+        ragged = hasattr(generator, "forward_ragged")  # every engine takes ragged batches (round 5: fp32 and bf16x3 too — the parity-grade pipeline)
         if overlap_groups is None:
             overlap_groups = OVERLAP_GROUPS
         if not ragged:
