@@ -226,7 +226,17 @@ def pmc_counters(kernel: str, args, B: int, T: int):
     return traffic, util, None
 
 
-def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=1, passes=3, nat_bf16x3=False):
+def _parity_golden():
+    """tests/golden/bench_parity_grade.npz (minted by oracle/make_bench_golden.py, a committed fixture: the oracle itself is imported by the
+    cpu_baseline leg only): the fp64 oracle CHAIN's waveforms for three transcript sentences of the pipeline workload and the fp64 oracle
+    generator's samples on three windows of the long-form utterance."""
+    try:
+        return np.load(os.path.join(REPO, "tests", "golden", "bench_parity_grade.npz"))
+    except OSError:
+        return None
+
+
+def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, passes=3, nat_bf16x3=False, golden=None):
     """BASELINE.json configs[3]: n sentences cycled from the reference's demo transcript x the InfoRe lexicon (SURVEY.md §8d;
     fixtures tests/golden/text/, token ids pinned to the reference's own text2tokens) with synthetic checkpoints -> NAT
     duration model -> frame rules -> NAT acoustic model (prenet dropout on, masks drawn on the device) -> HiFi-GAN bf16 in
@@ -267,7 +277,7 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=
         if barrier:
             barrier()
         t0 = time.perf_counter()
-        wavs = synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, dropout_seed=7, rank=rank, world=world, timing=tm, overlap_groups=overlap_groups)
+        wavs = synthesize_sentences(sents, dm, am, gen, silence_duration=0.05, dropout_seed=7, rank=rank, world=world, timing=tm)
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
         nsamp = int(sum(w.shape[0] for w in wavs.values()))
@@ -275,13 +285,26 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, overlap_groups=
                            f"text tokens -> 16 kHz waveform, sharded over {world} GPU(s) with no exchange step",
                "sentences": n, "tokens": tm.get("tokens", 0), "frames": tm.get("frames", 0), "frames_max": tm.get("frames_max", 0), "samples": nsamp,
                "duration_model_ms": tm.get("duration_s", 0.0) * 1e3, "host_rules_ms": tm.get("host_rules_s", 0.0) * 1e3,
-               # overlap_groups > 1: the acoustic model runs on a stream of its own UNDER the generator (no synchronisation between the two stages), so
-               # only the host's enqueue time of the acoustic model is separable; generator_ms then covers everything from there to the last sample
-               # (0.0 = not applicable to the schedule this rank ran)
-               "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3, "acoustic_enqueue_ms": tm.get("acoustic_enqueue_s", 0.0) * 1e3,
+               "acoustic_model_ms": tm.get("acoustic_s", 0.0) * 1e3,
                "acoustic_precision": "bf16x3 option" if nat_bf16x3 else "fp32",
-               "overlap_groups": tm.get("overlap_groups", 1), "pinned_alloc_ms": tm.get("pinned_alloc_s", 0.0) * 1e3,
+               "pinned_alloc_ms": tm.get("pinned_alloc_s", 0.0) * 1e3,
                "generator_ms": tm.get("generator_s", 0.0) * 1e3, "total_ms": total * 1e3}
+    if golden is not None and wavs is not None and "total_ms" in out:
+        # in-run check of the timed pass's own waveforms against the fp64 oracle chain (text tokens -> duration model -> frame rules -> acoustic model
+        # on the same dropout masks -> generator; vietTTS/synthesizer.py:33-39) for the fixture's sentences this rank owns; equal integer frame counts
+        worst, checked, frames_equal = 0.0, 0, True
+        for i in (int(v) for v in golden["pipe_sentences"]):
+            if i in wavs:
+                want = golden[f"pipe_{i}_wave"]
+                nfr, trail = (int(v) for v in golden[f"pipe_{i}_frames"])
+                if wavs[i].shape[0] != 256 * (nfr - trail) or list(sents[i]) != [int(v) for v in golden[f"pipe_{i}_tokens"]]:
+                    frames_equal = False
+                    continue
+                worst = max(worst, float(np.abs(wavs[i].astype(np.float64) - want).max()))
+                checked += 1
+        out["max_abs_vs_oracle_chain"] = worst if checked else None
+        out["oracle_chain_sentences_checked"] = checked
+        out["integer_frame_counts_equal"] = frames_equal
     dm.close()
     am.close()
     if own:
@@ -395,49 +418,82 @@ def main():
     gen.set_option("streams", saved[0])
     gen.set_option("microbatch", saved[1])
 
-    # ---- text -> waveform (BASELINE configs[3]): 256 sentences sharded over the ranks; whole job = max over ranks ----
-    pipe = None
-    if not args.no_rtf and args.dtype == "bf16":
+    def run_pipeline(g, **kw):
+        """One pipeline_256 job on generator g, this rank's shard; the ranks' numbers combined (times: max, counts: sum, errors: max)."""
         try:
-            # the vocoder here is the bf16 engine (~1e-2 of a sample's range), so the acoustic model runs with its bf16x3 option (1e-5 of the mel's
-            # range: include/vtts_nat.h); `acoustic_fp32` below = the same job with every acoustic product in fp32 (the mode pinned to the reference at 5e-5)
-            pipe = pipeline_256(256, gen, info.rank, n_gpus, barrier, nat_bf16x3=True)
+            p = pipeline_256(256, g, info.rank, n_gpus, barrier, **kw)
         except Exception as e:  # a side measurement must not take the headline line down with it
-            pipe = {"error": f"{type(e).__name__}: {e}"}
+            p = {"error": f"{type(e).__name__}: {e}"}
         if n_gpus > 1:  # the ranks agree on whether to combine (a failed rank would otherwise leave the others in a collective)
-            ok = torch.tensor([0.0 if "error" in pipe else 1.0], dtype=torch.float64, device=dev)
+            ok = torch.tensor([0.0 if "error" in p else 1.0], dtype=torch.float64, device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if ok.item() < 1.0 and "error" not in pipe:
-                pipe = {"error": "another rank failed"}
-        if n_gpus > 1 and "error" not in pipe:
-            keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "acoustic_enqueue_ms", "generator_ms", "total_ms", "frames_max", "overlap_groups", "pinned_alloc_ms"]
+            if ok.item() < 1.0 and "error" not in p:
+                p = {"error": "another rank failed"}
+        if n_gpus > 1 and "error" not in p:
+            keys_max = ["duration_model_ms", "host_rules_ms", "acoustic_model_ms", "generator_ms", "total_ms", "frames_max", "pinned_alloc_ms"]
             keys_sum = ["tokens", "frames", "samples"]
-            tmax = torch.tensor([float(pipe[k]) for k in keys_max], dtype=torch.float64, device=dev)
-            tsum = torch.tensor([float(pipe[k]) for k in keys_sum], dtype=torch.float64, device=dev)
+            if "oracle_chain_sentences_checked" in p:
+                p["max_abs_vs_oracle_chain"] = p["max_abs_vs_oracle_chain"] or 0.0
+                p["integer_frame_counts_unequal"] = 0.0 if p.pop("integer_frame_counts_equal") else 1.0
+                keys_max += ["max_abs_vs_oracle_chain", "integer_frame_counts_unequal"]
+                keys_sum += ["oracle_chain_sentences_checked"]
+            tmax = torch.tensor([float(p[k]) for k in keys_max], dtype=torch.float64, device=dev)
+            tsum = torch.tensor([float(p[k]) for k in keys_sum], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
             for k, v in zip(keys_max, tmax.tolist()):
-                pipe[k] = int(v) if k in ("frames_max", "overlap_groups") else v
+                p[k] = int(v) if k == "frames_max" else v
             for k, v in zip(keys_sum, tsum.tolist()):
-                pipe[k] = int(v)
+                p[k] = int(v)
+            if "integer_frame_counts_unequal" in p:
+                p["integer_frame_counts_equal"] = p.pop("integer_frame_counts_unequal") == 0.0
+        if "error" not in p:
+            p["samples_per_s"] = p["samples"] / (p["total_ms"] * 1e-3)
+            p["sentences_per_s"] = p["sentences"] / (p["total_ms"] * 1e-3)
+        return p
+
+    # ---- text -> waveform (BASELINE configs[3]): 256 sentences sharded over the ranks; whole job = max over ranks ----
+    # Two peers (ADVICE r04): `pipeline_256` = the throughput configuration (bf16 vocoder ~1e-2 of a sample's range, so the acoustic model runs with
+    # its bf16x3 option, 1e-5 of the mel's range: include/vtts_nat.h), and `pipeline_256.parity_grade` = the configuration that answers to
+    # north_star's 1e-4: the split-operand (bf16x3) vocoder in ragged passes + the acoustic model in fp32, the mode pinned to the reference's code.
+    pipe = None
+    gx_side = None  # the split-operand generator of the parity-grade legs (every rank: the legs shard like their bf16 peers)
+    golden = _parity_golden()
+    if not args.no_rtf and args.dtype == "bf16" and not args.no_f32:
+        try:
+            gx_side = Generator(V1, device=dev, dtype="bf16x3")
+            vdist.setup_generator_dp(gx_side, lambda: synthetic_params(V1, 4321, "scaled"), info, {})
+        except Exception:
+            gx_side = None
+    if not args.no_rtf and args.dtype == "bf16":
+        pipe = run_pipeline(gen, nat_bf16x3=True)
         if "error" not in pipe:
-            pipe["samples_per_s"] = pipe["samples"] / (pipe["total_ms"] * 1e-3)
-            pipe["sentences_per_s"] = pipe["sentences"] / (pipe["total_ms"] * 1e-3)
+            pipe["vocoder"] = "bf16 engine"
+        if gx_side is not None and "error" not in pipe:
+            pg = run_pipeline(gx_side, nat_bf16x3=False, golden=golden)
+            if "error" not in pg:
+                pipe["parity_grade"] = {
+                    "what": "the same 256 sentences with the vocoder on the split-operand engine (bf16x3: <= 5e-5 of the reference generator on identical mels, "
+                            "tests/test_gpu_nat.py) in ragged passes and every acoustic product in fp32 (the mode pinned to the reference's code at 5e-5)",
+                    "vocoder": "bf16x3 engine", "acoustic_precision": "fp32",
+                    "total_ms": pg["total_ms"], "acoustic_model_ms": pg["acoustic_model_ms"], "generator_ms": pg["generator_ms"],
+                    "samples_per_s": pg["samples_per_s"], "sentences_per_s": pg["sentences_per_s"],
+                    # in-run, the timed pass's own waveforms: the fp64 oracle CHAIN end to end (acoustic model included; tests check the vocoder alone on
+                    # the same GPU mel at 5e-5), tests/golden/bench_parity_grade.npz
+                    "max_abs_vs_oracle_chain": pg.get("max_abs_vs_oracle_chain"), "oracle_chain_sentences_checked": pg.get("oracle_chain_sentences_checked"),
+                    "integer_frame_counts_equal": pg.get("integer_frame_counts_equal"),
+                    "reference": "oracle/make_bench_golden.py: nat_oracle.duration_model -> frame rules -> nat_oracle.acoustic_inference (fp64, same threefry masks) -> hifigan_oracle (fp64)",
+                }
+            else:
+                pipe["parity_grade"] = pg
         if n_gpus == 1 and "error" not in pipe:
-            # the opt-in overlapped schedule (acoustic model and generator side by side, mel handed over in 6 groups), same process: what it gains
-            # depends on how the runtime maps the streams to hardware queues (viettts_amd/pipeline.py), so it is reported, not assumed
+            # the throughput configuration with every acoustic product in fp32 (round 4's `acoustic_fp32`): what the acoustic model's option is worth
             try:
                 pf = pipeline_256(256, gen, info.rank, n_gpus, barrier)
                 pipe["acoustic_fp32"] = {"acoustic_model_ms": pf["acoustic_model_ms"], "generator_ms": pf["generator_ms"], "total_ms": pf["total_ms"],
                                          "samples_per_s": pf["samples"] / (pf["total_ms"] * 1e-3)}
             except Exception as e:
                 pipe["acoustic_fp32"] = {"error": f"{type(e).__name__}: {e}"}
-            try:
-                po = pipeline_256(256, gen, info.rank, n_gpus, barrier, overlap_groups=6, nat_bf16x3=True)
-                pipe["overlapped_schedule"] = {"overlap_groups": po["overlap_groups"], "total_ms": po["total_ms"], "generator_ms": po["generator_ms"],
-                                               "acoustic_enqueue_ms": po["acoustic_enqueue_ms"]}
-            except Exception as e:
-                pipe["overlapped_schedule"] = {"error": f"{type(e).__name__}: {e}"}
 
     # ---- long-form (BASELINE configs[4]): 10 min of 16 kHz audio, exact 512-frame chunks + 13-frame halo, chunk c -> rank c mod N ----
     longform = None
@@ -467,6 +523,43 @@ def main():
             "samples_per_s": 256 * T10 / total_s,
             "chunks": int(nchunks),
         }
+        if gx_side is not None:
+            try:
+                synthesize_chunked(gx_side, m10, 512, rank=info.rank, world=n_gpus)  # warm-up
+                torch.cuda.synchronize()
+                barrier()
+                tmx = {}
+                wx = synthesize_chunked(gx_side, m10, 512, rank=info.rank, world=n_gpus, timing=tmx)
+                # in-run: three windows of THIS pass's output (utterance start, the chunk seam at 512 * 37, utterance end) against the fp64 oracle generator
+                # (tests/golden/bench_parity_grade.npz); a rank checks the frames of the chunks it owns (chunk c -> rank c mod N)
+                err, nchk = 0.0, 0
+                if golden is not None:
+                    for name in ("start", "seam", "end"):
+                        lo = int(golden[f"lf_{name}_lo"])
+                        want = torch.from_numpy(golden[f"lf_{name}_wave"]).to(dev)
+                        got = wx[256 * lo : 256 * lo + want.numel()].double()
+                        fr = torch.arange(lo, lo + want.numel() // 256, device=dev)
+                        own = (((fr // 512) % n_gpus) == info.rank).repeat_interleave(256)
+                        if bool(own.any()):
+                            err = max(err, float((got - want).abs()[own].max()))
+                            nchk += int(own.sum())
+                tx = torch.tensor([tmx.get("first_chunk_s", 0.0), tmx["total_s"], err, float(nchk)], dtype=torch.float64, device=dev)
+                if n_gpus > 1:
+                    tmax, tsum = tx.clone(), tx.clone()
+                    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+                    tx = torch.stack([tmax[0], tmax[1], tmax[2], tsum[3]])
+                fx, totx, errx, nx = (float(v) for v in tx.tolist())
+                longform["parity_grade"] = {
+                    "what": "the same utterance and schedule on the split-operand engine (bf16x3; chunked == un-chunked bit for bit and <= 5e-5 of the fp64 oracle: tests/test_gpu_longform.py)",
+                    "vocoder": "bf16x3 engine", "first_chunk_ms": fx * 1e3, "total_ms": totx * 1e3, "rtf_16000": totx / 600.0, "samples_per_s": 256 * T10 / totx,
+                    "max_abs_vs_fp64_oracle_windows": errx if nx else None, "samples_compared": int(nx), "bar": 1e-4,
+                    "reference": "oracle/make_bench_golden.py: hifigan_oracle.generator_forward (fp64) on frames [lo - 13, hi + 13) of the utterance's mel, windows at the start, at the seam 512 x 37 and at the end",
+                }
+                del wx
+            except Exception as e:
+                longform["parity_grade"] = {"error": f"{type(e).__name__}: {e}"}
+        longform["vocoder"] = f"{args.dtype} engine"
         del m10
 
     assert bool(torch.isfinite(out).all()), "non-finite output"
@@ -701,6 +794,8 @@ def main():
 
     barrier()
     gen.close()
+    if gx_side is not None:
+        gx_side.close()
     if n_gpus > 1 and dist.is_initialized():
         dist.destroy_process_group()
 

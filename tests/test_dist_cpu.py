@@ -178,22 +178,6 @@ def test_generator_batches_bound_the_padded_size():
     assert all(len(b) * fr[b[-1]] <= 2 * PASS_FRAMES for b in out) and len(out) == 2
 
 
-def test_overlap_groups_are_contiguous_and_balanced():
-    """viettts_amd/pipeline.py::_overlap_groups — the row groups whose mel the acoustic model hands over one after another."""
-    import random
-
-    from viettts_amd.pipeline import _overlap_groups
-
-    rnd = random.Random(9)
-    for n, ng in ((256, 4), (12, 3), (5, 8), (1, 4), (64, 1)):
-        fr = sorted((rnd.randint(60, 281) for _ in range(n)), reverse=True)
-        b = _overlap_groups(fr, ng)
-        assert b[0] == 0 and b[-1] == n and all(x < y for x, y in zip(b, b[1:])) and len(b) - 1 <= max(1, min(ng, n))
-        if n == 256:
-            sums = [sum(fr[b[i] : b[i + 1]]) for i in range(len(b) - 1)]
-            assert len(sums) == 4 and max(sums) - min(sums) <= 2 * 281
-
-
 def test_gloo_world2_broadcast_and_gather():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")

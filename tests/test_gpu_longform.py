@@ -100,6 +100,45 @@ def test_chunked_equals_unchunked_bf16_default_pass(gen_bf16, T, chunk, with_ora
     assert torch.equal(synthesize_chunked(gen_bf16, mel[0], chunk_frames=chunk, max_batch=3), got)
 
 
+@pytest.mark.parametrize("dtype,bound", [("bf16x3", 5e-5), ("f32", 2e-5)])
+def test_chunked_equals_unchunked_parity_grade(dtype, bound, capsys):
+    """BASELINE configs[4] at north_star's tolerance (round 5): ``synthesize_chunked`` with its DEFAULTS on the split-operand engine (and the fp32
+    engine) — first chunk alone, one full-size pass, ragged last chunk, chunk-DP over two ranks — against
+    (a) the un-chunked output of the same engine (the 13-frame halo covers the +-12.71-frame receptive field: bit-identical on the split engine,
+        whose kernels do not depend on the chunk's length; the fp32 engine routes a length that is no multiple of 4 through the generic first
+        transposed convolution: ~1e-7),
+    (b) ``oracle.hifigan_oracle.generator_forward`` in fp64 on the whole utterance (vietTTS/hifigan/mel2wave.py:37-40) at the engine's bound."""
+    from oracle.hifigan_oracle import generator_forward
+    from viettts_amd.hifigan.generator import Generator
+    from viettts_amd.longform import synthesize_chunked
+
+    params = synthetic_params(V1, 4321, "scaled")
+    g = Generator(V1, device="cuda:0", dtype=dtype)
+    g.load_params(params)
+    try:
+        T, chunk = 700, 128
+        mel_h = synthetic_mel(1, T, 3)
+        mel = torch.from_numpy(mel_h).to("cuda:0")
+        full = g(mel)[0].clone()
+        timing = {}
+        got = synthesize_chunked(g, mel[0], chunk_frames=chunk, timing=timing)
+        assert got.shape == full.shape and timing["chunks"] == -(-T // chunk)
+        d_self, n_diff = float((got - full).abs().max()), int((got != full).sum())
+        want = generator_forward(params, mel_h, V1, np.float64)[0, :, 0]
+        e_or = float(np.abs(got.double().cpu().numpy() - want).max())
+        with capsys.disabled():
+            print(f"\n[{dtype} long-form T={T} chunk={chunk}] chunked vs un-chunked: max|d| {d_self:.3e} ({n_diff} samples differ); chunked vs fp64 oracle: {e_or:.3e}")
+        if dtype == "bf16x3":
+            assert torch.equal(got, full)
+        assert d_self < 2e-6 and e_or < bound
+        a = synthesize_chunked(g, mel[0], chunk_frames=chunk, rank=0, world=2)
+        b = synthesize_chunked(g, mel[0], chunk_frames=chunk, rank=1, world=2)
+        assert ((a != 0) & (b != 0)).sum().item() == 0 and torch.equal(a + b, got)
+        assert torch.equal(synthesize_chunked(g, mel[0], chunk_frames=chunk, max_batch=3), got)
+    finally:
+        g.close()
+
+
 def test_dp_setup_single_rank(gen):
     from viettts_amd import dist as vdist
     from viettts_amd.hifigan.generator import Generator

@@ -98,6 +98,24 @@ def test_x3_upsample_kat(gen, v1_params, dev, i, L, capsys):
     assert rel < 3e-5, (err, rel)
 
 
+@pytest.mark.parametrize("L", [1, 5, 64, 67, 300])
+def test_x3_conv_pre_kat(gen, v1_params, dev, L, capsys):
+    """conv_pre with split operands (conv_pre_x3_k, round 5) against the oracle's ``conv1d`` in fp64 (vietTTS/hifigan/model.py:83,110: 80 -> 512,
+    k = 7, pad 3, no activation in front): one frame, fewer frames than the halo, a whole tile, a ragged second tile, several tiles."""
+    spec = [s for s in conv_specs(V1) if s.key == "generator/~/conv1_d"][0]
+    x = synthetic_mel(2, L, 50 + L)
+    w, b = v1_params[spec.key]["w"].astype(np.float64), v1_params[spec.key]["b"].astype(np.float64)
+    ref = orc.conv1d(x.astype(np.float64), w, b, 1, 3)
+    y = gen.run_module(spec.key, torch.from_numpy(x).to(dev), 1.0)
+    torch.cuda.synchronize()
+    assert y.shape == (2, 512, L)
+    err = float(np.abs(_nwc(y.cpu().numpy()) - ref).max())
+    rel = err / float(np.abs(ref).max())
+    with capsys.disabled():
+        print(f"\n[bf16x3 conv_pre L={L}] max|err| {err:.3e} ({rel:.2e} of max|ref| {np.abs(ref).max():.2f})")
+    assert rel < 3e-5, (err, rel)
+
+
 @pytest.mark.parametrize("case", ["v1_scaled_T8", "v1_scaled_T37", "v1_scaled_T512"])
 def test_x3_generator_vs_reference_golden(golden_dir, gen, dev, case, capsys):
     """Whole generator against the reference generator's own fp64 output (tests/golden, minted by oracle/make_golden.py from

@@ -9,8 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import pipeline_256  # noqa: E402
 
 if __name__ == "__main__":
-    og = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # overlap groups: 1 = stages one after the other (the default), G > 1 = the opt-in overlapped schedule
-    r = pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256, overlap_groups=og, passes=int(sys.argv[3]) if len(sys.argv) > 3 else 2,
-                     nat_bf16x3=len(sys.argv) > 4 and sys.argv[4] == "x3")
+    # usage: pipeline_bench.py [sentences] [passes] [x3]     (x3 = the acoustic model's bf16x3 option)
+    r = pipeline_256(int(sys.argv[1]) if len(sys.argv) > 1 else 256, passes=int(sys.argv[2]) if len(sys.argv) > 2 else 2,
+                     nat_bf16x3=len(sys.argv) > 3 and sys.argv[3] == "x3")
     r["samples_per_s"] = r["samples"] / (r["total_ms"] * 1e-3)
     print(json.dumps(r))

@@ -10,7 +10,7 @@ cp gpurun_out/$TAG/counters_bf16.json gpurun_out/$TAG/counters_f32.json gpurun_o
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-700 $O/bench.json; tail -2 $O/bench.err
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 for mode in fp32 x3; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/pipe_$mode -o r -- python $R/tools/pipeline_bench.py 256 1 3 $mode > $R/gpurun_out/$TAG/pipe_$mode.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/pipe_$mode -o r -- python $R/tools/pipeline_bench.py 256 3 $mode > $R/gpurun_out/$TAG/pipe_$mode.log 2>&1
   python $R/tools/rocprof_summary.py $(find $R/gpurun_out/$TAG/pipe_$mode -name "*results.db" | head -1) $R/gpurun_out/$TAG/${TAG}_pipeline_${mode}_kernel_stats.md
   tail -1 $R/gpurun_out/$TAG/pipe_$mode.log | cut -c1-300
 done

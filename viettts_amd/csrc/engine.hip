@@ -335,6 +335,12 @@ int build_layers(vtts_hifigan* h) {
         }
     }
     if (h->x3) {
+        Layer& pre = h->layers[h->idx_pre];
+        if (conv_pre_x3_supported(pre.cin, pre.cout, pre.k, pre.dil)) {  // conv_pre on the split route too (round 5)
+            pre.has_x3 = true;
+            pre.off_x3 = off;
+            off = align_up(off + conv_pre_x3_bytes(), 256);
+        }
         for (int i : h->idx_ups) {
             Layer& l = h->layers[i];
             if (!convt_x3_supported(l.cin, l.cout, l.k, l.stride, l.pad_a, 4)) continue;
@@ -438,6 +444,13 @@ int run_layer(vtts_hifigan* h, const Layer& l, Act x, int B, int L, float slope_
             e = launch_conv1d_generic(a, s);
     } else {
         const bool nwc = x.sc == 1 && x.st == l.cin;
+        if (h->x3 && l.has_x3 && nwc && h->opt_kernels == 0 && h->opt_fuse >= 1 && !res && acc_mode == ACC_STORE && &l == &h->layers[h->idx_pre] &&
+            (reinterpret_cast<uintptr_t>(x.p) & 15) == 0) {  // (float4 row loads: a mel pointer that is not 16-byte aligned takes the fp32 kernel)
+            a.wp = h->blob + l.off_x3;  // VTTS_BF16X3: conv_pre with split operands (kernels_x3.hip: conv_pre_x3_k)
+            const hipError_t ex = launch_conv_pre_x3(a, s);
+            if (ex != hipSuccess) return fail(VTTS_ERR_HIP, "kernel launch for %s failed: %s", l.key.c_str(), hipGetErrorString(ex));
+            return VTTS_OK;
+        }
         const bool mfma = want_mfma && (ncw || nwc) && conv1d_f32_mfma_supported(l.cin, l.cout, l.k, l.dil, L, nwc);
         if (mfma) {
             const bool prof = h->opt_profile && l.cin == h->prof_C && l.cout == h->prof_C && l.k == h->prof_K;
@@ -1347,7 +1360,8 @@ VTTS_API int vtts_hifigan_pack(vtts_hifigan* h, void* dev_blob, size_t blob_byte
         if (h->dtype == VTTS_BF16) break;
         memcpy(host.data() + l.off_w, l.w.data(), l.w.size() * sizeof(float));
         memcpy(host.data() + l.off_b, l.b.data(), l.b.size() * sizeof(float));
-        if (l.has_x3 && l.kind == KIND_CONVT) convt_x3_pack(l.w.data(), l.cin, l.cout, l.k, l.stride, l.pad_a, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
+        if (l.has_x3 && &l == &h->layers[h->idx_pre]) conv_pre_x3_pack(l.w.data(), reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
+        else if (l.has_x3 && l.kind == KIND_CONVT) convt_x3_pack(l.w.data(), l.cin, l.cout, l.k, l.stride, l.pad_a, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
         else if (l.has_x3) pair_x3_pack(l.w.data(), l.cin, l.k, reinterpret_cast<unsigned short*>(host.data() + l.off_x3));
         if (l.has_wp && l.kind == KIND_CONV)
             conv1d_f32_mfma_pack(l.w.data(), l.cin, l.cout, l.k, reinterpret_cast<float*>(host.data() + l.off_wp));

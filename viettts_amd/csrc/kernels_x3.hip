@@ -686,4 +686,175 @@ hipError_t launch_convt_x3(const ConvArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
 }
 
+
+// =====================================================================================================
+// conv_pre (model.py:83,110: hk.Conv1D(512, 7, padding 3) on the mel, no activation in front) with split operands — the split engine's last fp32
+// MFMA launch until round 5.  mel [B][T][80] fp32 NWC (the boundary layout: a tile's rows are one contiguous run of 320-byte rows) ->
+// y [B][512][T] fp32 channel-major.  GEMM: M = 512 output channels, N = time, K = 7 taps x 80 mel bins = 35 k-steps of 16.
+// One workgroup = 8 waves = all 512 channels x 64 time steps (wave tile 64 x 64); the mel tile (70 rows x 80 bins) is split while staging into
+// a HI and a LO channels-last bf16 tile (10 slots of 16 bytes per row, stored in blocks of 16 rows as bf16_common.h: tile_off does for narrow rows);
+// the taps are shifted row views of it; weights [plane][tap][ks][mblk][lane][8] straight from L2 (1.1 MB, every workgroup reads all of it:
+// L2 / Infinity-Cache resident); epilogue: + bias, fp32 stores in the accumulator layout (a half-wave = 32 consecutive time steps of one channel).
+// =====================================================================================================
+struct PreX3 {
+    static constexpr int CIN = 80, COUT = 512, KS = 7, H = 3, N1 = 64, WM = 8, WN = 1;
+    static constexpr int THREADS = 64 * WM * WN, MR = COUT / WM / 32, NR = N1 / WN / 32;
+    static constexpr int SPR = CIN / 8, KSTEPS = CIN / 16, MB = COUT / 32;
+    static constexpr int ROWS = N1 + 2 * H;
+    static constexpr int PLANE = tile_rows16(ROWS) * CIN * 2;
+    static constexpr int LDS_BYTES = 2 * PLANE;
+    static constexpr size_t PLANE_W = (size_t)KS * KSTEPS * MB * 1024;  // bytes of one weight plane
+    static constexpr int NSTEPS = KS * KSTEPS;
+};
+
+__global__ __launch_bounds__(PreX3::THREADS, 2) void conv_pre_x3_k(ConvArgs a) {
+    using T = PreX3;
+    constexpr int CIN = T::CIN, COUT = T::COUT, N1 = T::N1, MR = T::MR, NR = T::NR, SPR = T::SPR, KSTEPS = T::KSTEPS, MB = T::MB, ROWS = T::ROWS, NSTEPS = T::NSTEPS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const thi = lds;
+    unsigned char* const tlo = lds + T::PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int b = a.zrev ? (int)(gridDim.z - 1 - blockIdx.z) : (int)blockIdx.z;
+    const int LP = a.L;             // frames allocated per utterance (row pitch of y)
+    const int L = valid_len(a, b);  // this utterance's frames
+    const int t0 = blockIdx.x * N1;
+    if (t0 >= L) return;
+    const float* __restrict__ xb = a.x + (long)b * a.x_sb;  // [T][80]
+    const float slope = a.slope_in;                           // 1 for conv_pre (identity); kept general
+    auto split2 = [](float v0, float v1, unsigned& hi, unsigned& lo) {
+        hi = pack_bf16x2(v0, v1);
+        lo = pack_bf16x2(v0 - bf16_lo(hi), v1 - bf16_hi(hi));
+    };
+    // ---- mel tile: frames t0 - 3 .. t0 + N1 + 2 (zero outside the utterance), unit = (row, 8 bins): two float4 loads of a contiguous row ----
+    for (int u = tid; u < ROWS * SPR; u += T::THREADS) {
+        const int row = u / SPR, slot = u - row * SPR;
+        const int t = t0 - T::H + row;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (t >= 0 && t < L) {
+            const float4* g = reinterpret_cast<const float4*>(xb + (long)t * CIN + slot * 8);  // 320-byte rows: 16-byte aligned
+            v0 = g[0];
+            v1 = g[1];
+        }
+        uint4 h4, l4;
+        split2(lrelu(v0.x, slope), lrelu(v0.y, slope), h4.x, l4.x);
+        split2(lrelu(v0.z, slope), lrelu(v0.w, slope), h4.y, l4.y);
+        split2(lrelu(v1.x, slope), lrelu(v1.y, slope), h4.z, l4.z);
+        split2(lrelu(v1.z, slope), lrelu(v1.w, slope), h4.w, l4.w);
+        const int off = tile_off<SPR>(row, slot);
+        *reinterpret_cast<uint4*>(thi + off) = h4;
+        *reinterpret_cast<uint4*>(tlo + off) = l4;
+    }
+    __syncthreads();
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+    const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wp), 0, (int)(2 * T::PLANE_W), 0x00020000);
+    const unsigned a_voff = (unsigned)((wave * MR) * 64 + lane) * 16;
+    bf16x8 af[2][MR][2], bf[2][NR][2];
+    auto load_a = [&](int s, int slot) {
+        const int sc = s < NSTEPS ? s : NSTEPS - 1;
+        const int soff = (sc * MB) * 1024;  // step = tap * KSTEPS + ks
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr) {
+            af[slot][mr][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + mr * 1024, soff, 0));
+            af[slot][mr][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + mr * 1024, soff + (int)T::PLANE_W, 0));
+        }
+    };
+    auto load_b = [&](int s, int par) {
+        const int sc = s < NSTEPS ? s : NSTEPS - 1;
+        const int tap = sc / KSTEPS, ks = sc - tap * KSTEPS;
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int off = tile_off<SPR>(l31 + tap + nr * 32, ks * 2 + lh);  // output column n, tap j reads tile row n + j
+            bf[par][nr][0] = *reinterpret_cast<const bf16x8*>(thi + off);
+            bf[par][nr][1] = *reinterpret_cast<const bf16x8*>(tlo + off);
+        }
+    };
+    load_a(0, 0);
+    load_b(0, 0);
+#pragma unroll 1
+    for (int s = 0; s < NSTEPS; ++s) {
+        const int cur = s & 1;
+        // (the ring slot is a runtime parity here: 35 steps; both branches are the same code on swapped registers)
+        if (cur == 0) {
+            load_a(s + 1, 1);
+            load_b(s + 1, 1);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][mr][term == 0 ? 1 : 0], bf[0][nr][term == 1 ? 1 : 0], acc[mr][nr], 0, 0, 0);
+        } else {
+            load_a(s + 1, 0);
+            load_b(s + 1, 0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][mr][term == 0 ? 1 : 0], bf[1][nr][term == 1 ? 1 : 0], acc[mr][nr], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: + bias, fp32 channel-major stores ----
+    float* yb = a.y + (long)b * COUT * LP;
+#pragma unroll
+    for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int t = t0 + nr * 32 + l31;
+            if (t >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (wave * MR + mr) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                yb[(long)co * LP + t] = acc[mr][nr][r] + a.bias[co];
+            }
+        }
+}
+
+bool conv_pre_x3_supported(int Cin, int Cout, int K, int dil) { return Cin == PreX3::CIN && Cout == PreX3::COUT && K == PreX3::KS && dil == 1; }
+size_t conv_pre_x3_bytes() { return 2 * PreX3::PLANE_W; }
+
+// Haiku [K][Cin][Cout] fp32 -> [plane][tap][ks][mblk][lane][8] bf16: row m = mblk*32 + (lane & 31) = co, k = ks*16 + 8*(lane >> 5) + e = ci
+void conv_pre_x3_pack(const float* w_hk, unsigned short* out) {
+    using T = PreX3;
+    const size_t plane = T::PLANE_W / 2;  // elements
+    for (int tap = 0; tap < T::KS; ++tap)
+        for (int ks = 0; ks < T::KSTEPS; ++ks)
+            for (int mb = 0; mb < T::MB; ++mb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int co = mb * 32 + (lane & 31), ci = ks * 16 + 8 * (lane >> 5) + e;
+                        const float w = w_hk[((size_t)tap * T::CIN + ci) * T::COUT + co];
+                        unsigned u;
+                        memcpy(&u, &w, 4);
+                        const unsigned uh = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+                        float hi;
+                        memcpy(&hi, &uh, 4);
+                        const float lo = w - hi;
+                        unsigned ul;
+                        memcpy(&ul, &lo, 4);
+                        ul = (ul + 0x7fffu + ((ul >> 16) & 1u)) >> 16;
+                        const size_t o = ((((size_t)tap * T::KSTEPS + ks) * T::MB + mb) * 64 + lane) * 8 + e;
+                        out[o] = (unsigned short)(uh >> 16);
+                        out[plane + o] = (unsigned short)ul;
+                    }
+}
+
+// a.x = mel [B][L][80] (a.x_sb = batch stride), a.y [B][512][L], a.wp = conv_pre_x3_pack's output, a.bias [512]
+hipError_t launch_conv_pre_x3(const ConvArgs& a, hipStream_t s) {
+    static DynLdsOnce once;
+    if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&conv_pre_x3_k), PreX3::LDS_BYTES, once); e != hipSuccess) return e;
+    dim3 grid((a.L + PreX3::N1 - 1) / PreX3::N1, 1, a.B);
+    hipLaunchKernelGGL(conv_pre_x3_k, grid, dim3(PreX3::THREADS), PreX3::LDS_BYTES, s, a);
+    return hipGetLastError();
+}
+
 }  // namespace vtts

@@ -94,6 +94,11 @@ bool convt_x3_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
 size_t convt_x3_bytes(int Cin, int Cout, int stride);
 void convt_x3_pack(const float* w_hk, int Cin, int Cout, int K, int stride, int pad_a, unsigned short* out);
 hipError_t launch_convt_x3(const ConvArgs& a, hipStream_t s);
+// ... and conv_pre (80 -> 512, k = 7, mel NWC in): a.x [B][L][80] (a.x_sb = the batch stride), a.y [B][512][L], a.wp = conv_pre_x3_pack's output
+bool conv_pre_x3_supported(int Cin, int Cout, int K, int dil);
+size_t conv_pre_x3_bytes();
+void conv_pre_x3_pack(const float* w_hk, unsigned short* out);
+hipError_t launch_conv_pre_x3(const ConvArgs& a, hipStream_t s);
 
 // ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
 bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);

@@ -8,8 +8,9 @@ and keeps its waveforms.  The only collectives of the whole job are the three st
     tokens --DurationModel--> seconds/token --rules (text2mel.py:90-97)--> frames --AcousticModel--> mel --Generator--> wav
 with the generator fed ragged batches (sentences sorted by length, each batch padded to its longest; every engine — bf16, and since
 round 5 fp32 and bf16x3, the ones that answer to the reference's 1e-4 — gives every utterance the zero padding it would see alone and
-skips the tiles past its end); optionally the last two stages
-overlap: the acoustic model hands its mel over in groups as the decoder finishes them (synthesize_sentences, overlap_groups).
+skips the tiles past its end).  (Round 4 also carried an opt-in schedule that overlapped the last two stages on streams of
+their own; it measured 3 % faster or 30 % slower depending on how the runtime mapped streams to hardware queues — 68.0 against 51.2 ms on
+the round's driver box — and was deleted in round 5: profiles/r04_c_kernel_structure_findings.md)
 """
 from __future__ import annotations
 
@@ -69,57 +70,25 @@ def _generator_batches(rows: Sequence[int], frames: Sequence[int], gen_batch: in
     return out
 
 
-def _overlap_groups(frames_desc: Sequence[int], ngroups: int) -> List[int]:
-    """Row boundaries ``[0, ..., n]`` of ``ngroups`` contiguous groups of a list of frame counts sorted in DESCENDING order, the groups
-    balanced by frames (the last group — the shortest sentences — is the first whose mel the decoder completes)."""
-    n = len(frames_desc)
-    ngroups = max(1, min(int(ngroups), n))
-    total = float(sum(frames_desc))
-    bounds, acc = [0], 0.0
-    for i, f in enumerate(frames_desc):
-        acc += f
-        if len(bounds) < ngroups and acc >= total * len(bounds) / ngroups and i + 1 < n and n - (i + 1) >= ngroups - len(bounds):
-            bounds.append(i + 1)
-    while len(bounds) < ngroups:  # degenerate inputs (many zero-frame rows): fall back to fewer groups
-        ngroups -= 1
-    bounds.append(n)
-    return bounds
-
-
 _SIDE_STREAMS: dict = {}
 
 
-def _side_streams(device: torch.device):
-    """(acoustic stream — high priority: its per-frame launches are short and latency-bound, and must not queue behind the generator's
-    thousands of workgroups —, copy stream) of a device, created once."""
+def _copy_stream(device: torch.device):
+    """The stream a pass's waveforms leave on (pinned host memory) while the next pass computes; one per device, created once."""
     key = (device.type, device.index)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = (torch.cuda.Stream(device=device, priority=-1), torch.cuda.Stream(device=device))
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]
-
-
-OVERLAP_GROUPS = 6  # groups of the opt-in overlapped schedule (256 transcript sentences on one MI355X: 4 groups 65.1-65.4 ms, 6 groups 63.8-63.9, 8 groups 64.6)
 
 
 def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, acoustic_model, generator, silence_duration: float = -1.0,
                          dropout_seed: Optional[int] = 0, rank: int = 0, world: int = 1, gen_batch: int = 0,
-                         timing: Optional[dict] = None, overlap_groups: Optional[int] = 1) -> Dict[int, np.ndarray]:
+                         timing: Optional[dict] = None) -> Dict[int, np.ndarray]:
     """Waveforms (float32, 16 kHz samples) of THIS rank's sentences, keyed by sentence index.  ``timing`` (a dict) receives
-    wall seconds per stage.
-
-    **Schedules.**  ``overlap_groups = 1`` (the default): the stages one after the other on the caller's stream, the waveforms leaving for pinned
-    host memory on a copy stream.  ``overlap_groups = G > 1`` (opt-in, ``None`` = OVERLAP_GROUPS): the acoustic model and the generator overlap —
-    the decoder is a chain of ``max(frames)`` dependent steps of three short launches each (latency-bound; it uses a fraction of the chip), the
-    generator a few dozen chip-filling launches (power-bound).  The sentences, sorted longest first, are cut into G contiguous groups balanced
-    by frames; the acoustic model runs on a high-priority stream of its own and hands a group's mel over as soon as the decoder has produced the
-    group's last frame (include/vtts_nat.h: vtts_nat_acoustic_forward_groups — the postnet of that group on a side stream), and the generator
-    consumes the groups shortest first on the caller's stream.  Masks are seeded by the GLOBAL sentence index and every stage computes a row
-    independently of its batch, so the samples do not depend on the schedule (tests/test_gpu_nat.py: bit-identical to each sentence alone).
-    Why it is not the default (round 4, 256 transcript sentences on one MI355X): what the overlap gains is bounded by the sentences' length
-    spread — nothing is ready before the shortest group's last frame, ~200 of 281 steps in — and what it costs depends on how the runtime maps
-    the streams to hardware queues: 63.8 ms against 65.8 one after the other when the decoder's launches keep their priority, **86 ms** when
-    they queue behind the generator's workgroups (the same code after a large generator pass had created the engine's side streams first;
-    GPU_MAX_HW_QUEUES=2 restores 64.6: gpurun_out/r04 diag_bench_pipe).  A 3 % gain that can turn into a 30 % loss stays opt-in."""
+    wall seconds per stage.  The stages run one after the other on the caller's stream; a pass's waveforms leave for pinned host memory
+    on a copy stream while the next pass computes.  Masks are seeded by the GLOBAL sentence index and every stage computes a row
+    independently of its batch, so the samples depend neither on the shard nor on the batch (tests/test_gpu_nat.py: bit-identical to each
+    sentence alone).  ``generator`` may be any engine: bf16 (throughput; ~1e-2), bf16x3 or f32 (the reference's 1e-4)."""
     import time
 
     def mark(name, t_prev, sync=True):
@@ -151,7 +120,7 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         ev_dur = torch.cuda.Event()
         ev_dur.record(cur0)
         enc_all = acoustic_model.encode(toks)
-        s_cp = _side_streams(torch.device(dev0) if not isinstance(dev0, torch.device) else dev0)[1]
+        s_cp = _copy_stream(torch.device(dev0) if not isinstance(dev0, torch.device) else dev0)
         s_cp.wait_event(ev_dur)
         with torch.cuda.stream(s_cp):
             sec_host = torch.empty(sec_dev.shape, dtype=sec_dev.dtype, pin_memory=True)
@@ -176,71 +145,46 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     if ok:
         dev = generator.device
         ragged = hasattr(generator, "forward_ragged")  # every engine takes ragged batches (round 5: fp32 and bf16x3 too — the parity-grade pipeline)
-        if overlap_groups is None:
-            overlap_groups = OVERLAP_GROUPS
-        if not ragged:
-            overlap_groups = 1
-        bounds = _overlap_groups([nfr[k] for k in ok], overlap_groups if hasattr(acoustic_model, "wait_group") else 1)
-        ngroups = len(bounds) - 1
         cur = torch.cuda.current_stream(dev)
-        s_ac, s_copy = _side_streams(dev)
-        ev_ac_end = torch.cuda.Event(enable_timing=False)
+        s_copy = _copy_stream(dev)
         # prenet dropout (on at inference, model.py:95-100): masks drawn on the GPU, seeded by the sentence's GLOBAL index.
         # The mel stays in HBM: [len(ok), Fmax, 80] on the device, rows past a sentence's frames zero.
         seeds = None if dropout_seed is None else [dropout_seed + mine[k] for k in ok]
         enc_kw = {}
         if enc_all is not None:
             enc_kw["encoded"] = enc_all.index_select(0, torch.tensor(ok, dtype=torch.long, device=enc_all.device))  # a device-side gather (plumbing)
-        if ngroups > 1:
-            s_ac.wait_stream(cur)
-            if enc_kw:
-                enc_kw["encoded"].record_stream(s_ac)
-            with torch.cuda.stream(s_ac):
-                mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False,
-                                         group_row0=bounds, **enc_kw)
-                ev_ac_end.record(s_ac)
-            mel_dev.record_stream(cur)
-            t_last = mark("acoustic_enqueue_s", t_last, sync=False)
-        else:
-            mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False, **enc_kw)
-            t_last = mark("acoustic_s", t_last)
+        mel_dev = acoustic_model([toks[k] for k in ok], [frames[k] for k in ok], [nfr[k] for k in ok], dropout_seeds=seeds, to_host=False, **enc_kw)
+        t_last = mark("acoustic_s", t_last)
         # the generator takes ragged batches (vtts_hifigan_forward_ragged: each utterance's samples are those of running it
-        # alone): a group's sentences sorted by length, cut into passes by _generator_batches, each cut to its longest
+        # alone): the sentences sorted by length, cut into passes by _generator_batches, each cut to its longest
         pending = []
         pf = _pass_frames(generator)
-        for g in range(ngroups - 1, -1, -1):  # the shortest sentences' group is complete first
-            if ngroups > 1:
-                acoustic_model.wait_group(g, cur)
-            todo = sorted((r for r in range(bounds[g], bounds[g + 1]) if gfr[ok[r]] > 0), key=lambda r: gfr[ok[r]])
-            for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, pf):
-                fr = [gfr[ok[r]] for r in rows]
-                batch = mel_dev[torch.tensor(rows, device=dev), : max(fr)].contiguous()  # a device-side gather (plumbing)
-                w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
-                # pinned, on a copy stream: the next pass computes while this one's samples leave
-                done = torch.cuda.Event()
-                done.record(cur)
-                t_pin = time.perf_counter()
-                host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
-                if timing is not None:
-                    timing["pinned_alloc_s"] = timing.get("pinned_alloc_s", 0.0) + time.perf_counter() - t_pin  # ~0 when the caching host allocator has a block
-                if os.environ.get("VTTS_PIPE_COPY_ON_CUR"):  # diagnostic switch: the read-back on the generator's own stream
+        todo = sorted((r for r in range(len(ok)) if gfr[ok[r]] > 0), key=lambda r: gfr[ok[r]])
+        for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, pf):
+            fr = [gfr[ok[r]] for r in rows]
+            batch = mel_dev[torch.tensor(rows, device=dev), : max(fr)].contiguous()  # a device-side gather (plumbing)
+            w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
+            # pinned, on a copy stream: the next pass computes while this one's samples leave
+            done = torch.cuda.Event()
+            done.record(cur)
+            t_pin = time.perf_counter()
+            host = torch.empty(w.shape, dtype=w.dtype, pin_memory=True)
+            if timing is not None:
+                timing["pinned_alloc_s"] = timing.get("pinned_alloc_s", 0.0) + time.perf_counter() - t_pin  # ~0 when the caching host allocator has a block
+            if os.environ.get("VTTS_PIPE_COPY_ON_CUR"):  # diagnostic switch: the read-back on the generator's own stream
+                host.copy_(w, non_blocking=True)
+            else:
+                s_copy.wait_event(done)
+                with torch.cuda.stream(s_copy):
                     host.copy_(w, non_blocking=True)
-                else:
-                    s_copy.wait_event(done)
-                    with torch.cuda.stream(s_copy):
-                        host.copy_(w, non_blocking=True)
-                    w.record_stream(s_copy)
-                pending.append((rows, fr, host))
-        if ngroups > 1:
-            cur.wait_stream(s_ac)
+                w.record_stream(s_copy)
+            pending.append((rows, fr, host))
         cur.wait_stream(s_copy)
         torch.cuda.synchronize()
         for rows, fr, host in pending:
             hn = host.numpy()
             for q, r in enumerate(rows):
                 wavs[mine[ok[r]]] = hn[q, : generator.hop * fr[q]]  # a view of the batch's pinned buffer (kept alive by the view)
-        if timing is not None:
-            timing["overlap_groups"] = ngroups
     else:
         t_last = mark("acoustic_s", t_last)
     t_last = mark("generator_s", t_last)
