@@ -172,6 +172,29 @@ def test_x3_edge_lengths_and_microbatches(gen, v1_params, dev):
     assert not torch.equal(f32, base) and float((f32 - base).abs().max()) < BOUND
 
 
+@pytest.mark.parametrize("T", [3, 37, 300])
+def test_x3_whole_resblock_equals_the_pair_path(gen, dev, T):
+    """resblock_x3_k (kernels_x3_rb.hip, round 5): the three pairs of a ResBlock and the MRF bookkeeping in one launch, the running x in registers.
+    Per output element it performs the pair kernel's operations in the pair kernel's order, so the whole generator is BIT-IDENTICAL with the
+    kernel off (fuse = 1: pairs only), at its default policy (fuse = 2: C = 32, and C = 64 at k = 3) and wherever it exists (fuse = 3) — on plain
+    and on ragged batches, at the stage taps and on the waveform.  T = 3: windows shorter than every margin; 37, 300: several windows, both edges."""
+    mel = torch.from_numpy(synthetic_mel(2, T, 300 + T)).to(dev)
+    frames = [T, max(1, T - 2)]
+    outs = {}
+    try:
+        for fuse in (1, 2, 3):
+            gen.set_option("fuse", fuse)
+            w = gen(mel).clone()
+            _, m2 = gen.forward_tap(mel, "mrf_2")
+            _, m3 = gen.forward_tap(mel, "mrf_3")
+            outs[fuse] = (w, m2.clone(), m3.clone(), gen.forward_ragged(mel, frames).clone())
+    finally:
+        gen.set_option("fuse", 2)
+    for fuse in (2, 3):
+        for got, want, what in zip(outs[fuse], outs[1], ("wav", "mrf_2", "mrf_3", "ragged wav")):
+            assert torch.equal(got, want), (fuse, what, float((got - want).abs().max()))
+
+
 def test_x3_other_architectures_run_on_the_fp32_kernels(dev):
     """Shapes the split kernels do not cover (the TINY fixtures' channel counts, ResBlock2 generators) run on the fp32 engine's kernels under the
     same handle type: bit-identical to an fp32 handle."""

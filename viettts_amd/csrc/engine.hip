@@ -585,6 +585,49 @@ int run_pair_x3(vtts_hifigan* h, const Layer& c1, const Layer& c2, const float* 
     return VTTS_OK;
 }
 
+// VTTS_BF16X3: a whole ResBlock1 (three pairs + the MRF bookkeeping) in one launch where the kernel exists and is the faster choice
+// (kernels_x3_rb.hip; fuse = 2: C = 32 and C = 64, k = 3; fuse = 3: wherever it exists); bit-identical to the three pair launches
+bool resblock_x3_wanted(const vtts_hifigan* h, const Layer* rb, int L) {
+    if (!h->x3 || h->opt_kernels != 0 || h->opt_fuse < 2) return false;
+    for (int q = 0; q < 6; ++q)
+        if (!rb[q].has_x3 || rb[q].cin != rb[0].cin || rb[q].cout != rb[0].cin || rb[q].k != rb[0].k || ((q & 1) && rb[q].dil != 1)) return false;
+    const int dils[3] = {rb[0].dil, rb[2].dil, rb[4].dil};
+    if (!resblock_x3_supported(rb[0].cin, rb[0].k, dils, L)) return false;
+    return h->opt_fuse >= 3 || resblock_x3_preferred(rb[0].cin, rb[0].k);
+}
+
+int run_resblock_x3(vtts_hifigan* h, const Layer* rb, const float* x, int B, int L, float* y, int acc_mode, float div, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.x_sb = (long)rb[0].cin * L;
+    a.x_sc = L;
+    a.x_st = 1;
+    a.y = y;
+    a.B = B;
+    a.Cin = rb[0].cin;
+    a.Cout = rb[0].cin;
+    a.K = rb[0].k;
+    a.stride = 1;
+    a.L = L;
+    a.Lout = L;
+    a.slope_in = 0.1f;  // LRELU_SLOPE (model.py:46,48)
+    a.acc_mode = acc_mode;
+    a.div = div;
+    a.zrev = next_zrev(h);
+    set_ragged(h, a, L);
+    const int dils[3] = {rb[0].dil, rb[2].dil, rb[4].dil};
+    const void* w[6];
+    const float* bias[6];
+    for (int q = 0; q < 6; ++q) {
+        w[q] = h->blob + rb[q].off_x3;
+        bias[q] = reinterpret_cast<const float*>(h->blob + rb[q].off_b);
+    }
+    hipError_t e = launch_resblock_x3(a, dils, w, bias, s);
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "split-operand ResBlock launch for %s failed: %s", rb[0].key.c_str(), hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 // ---- bf16 path -------------------------------------------------------------------------------------
 // ragged batches (vtts_hifigan_forward_ragged): every layer learns each utterance's valid rows = frames * (rows per frame)
 void set_ragged(const vtts_hifigan* h, BConvArgs& a, int L) {
@@ -1086,6 +1129,8 @@ int forward_impl(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                     }
                     return rcc;
                 }
+                if (resblock_x3_wanted(h, &h->layers[base], (int)L))  // VTTS_BF16X3, narrow stages: the whole ResBlock X -> out in one launch
+                    return run_resblock_x3(h, &h->layers[base], cur, nb, (int)L, out, mode, div, cs);
                 if (pair_x3_wanted(h, h->layers[base], h->layers[base + 1], (int)L) && pair_x3_wanted(h, h->layers[base + 2], h->layers[base + 3], (int)L) &&
                     pair_x3_wanted(h, h->layers[base + 4], h->layers[base + 5], (int)L)) {
                     // VTTS_BF16X3: X -> T -> C -> out as the fused fp32 pairs below

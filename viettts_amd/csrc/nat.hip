@@ -1634,6 +1634,12 @@ __global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsig
 // mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 into the other parity's state.  One
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
+#ifndef VTTS_NAT_PKFMA
+#define VTTS_NAT_PKFMA 0
+#endif
+#ifndef VTTS_NAT_PK_NOP
+#define VTTS_NAT_PK_NOP 0
+#endif
 template <bool X3>  // X3: the state is the bf16x3 step's (two bf16 planes, nat_zxidx; `plane` elements apart); h = hi + lo exactly, p is split on its way out
 __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext,
                                                               const int* __restrict__ nframes, const float4* __restrict__ f1, const float4* __restrict__ f2,
@@ -1680,9 +1686,45 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     // weights in [row / 4][col][4] order (pack-time copies "…#k4"): one 16-byte load per lane = 4 consecutive rows of its
     // column, a wave's loads 1 KiB contiguous — dword loads made the step wait on the number of vector-memory instructions
     // a CU can issue (2 700 per workgroup and frame)
-    auto partial = [&](const float4* __restrict__ src, const float4* __restrict__ w4, int rows, int width, int col, int ch, int per) {
+    auto partial = [&](const float4* __restrict__ src, const float4* __restrict__ w4, int rows, int width, int col, int ch, int per, int phase_bit) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;  // per and rows are multiples of 4
+#if VTTS_NAT_PKFMA  // kernel-development builds ONLY (tools/experiments/r05/pkfma_bisect.sh): the packed-f32 form hipcc's SLP vectoriser made of this loop
+        // (v_pk_fma_f32 with src1 broadcast: sentences (0, 1) and (2, 3) as register pairs), written out, in the phases VTTS_NAT_PKFMA's bits name
+        // (1 = projection, 2 = prenet layer 1, 4 = prenet layer 2) — the round-4 miscompute beside the bf16 generator, bisected by phase
+        if (VTTS_NAT_PKFMA & phase_bit) {
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll 4
+            for (int k = ch * per; k < k1; k += 4) {
+                const float4 wv = w4[(size_t)(k >> 2) * width + col];
+                float4 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
+#if VTTS_NAT_PK_NOP  // bisect of the mechanism: wait states between the ARRIVAL of the loaded operands and the first packed instruction that reads them
+                // (bit 0: the LDS operands x, bit 1: the global-memory operand w; an asm that "modifies" a value forces its s_waitcnt in front of the asm)
+                float4 wq = wv;
+                if (VTTS_NAT_PK_NOP & 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w));
+#ifndef VTTS_NAT_PK_NOPSTR
+#define VTTS_NAT_PK_NOPSTR "s_nop 7\n\ts_nop 7"
+#endif
+                if (VTTS_NAT_PK_NOP & 2) asm volatile(VTTS_NAT_PK_NOPSTR : "+v"(wq.x), "+v"(wq.y), "+v"(wq.z), "+v"(wq.w));
+                if (VTTS_NAT_PK_NOP & 4) {  // a VALU copy of the loaded registers and NO wait states: the packed instruction then reads VALU-written registers
+                    float4 wc;
+                    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=&v"(wc.x), "=&v"(wc.y), "=&v"(wc.z), "=&v"(wc.w) : "v"(wq.x), "v"(wq.y), "v"(wq.z), "v"(wq.w));
+                    wq = wc;
+                }
+#define wv wq
+#endif
+                a01 = __builtin_elementwise_fma(f32x2_t{x0.x, x0.y}, f32x2_t{wv.x, wv.x}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x0.z, x0.w}, f32x2_t{wv.x, wv.x}, a23);
+                a01 = __builtin_elementwise_fma(f32x2_t{x1.x, x1.y}, f32x2_t{wv.y, wv.y}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x1.z, x1.w}, f32x2_t{wv.y, wv.y}, a23);
+                a01 = __builtin_elementwise_fma(f32x2_t{x2.x, x2.y}, f32x2_t{wv.z, wv.z}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x2.z, x2.w}, f32x2_t{wv.z, wv.z}, a23);
+                a01 = __builtin_elementwise_fma(f32x2_t{x3.x, x3.y}, f32x2_t{wv.w, wv.w}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x3.z, x3.w}, f32x2_t{wv.w, wv.w}, a23);
+#if VTTS_NAT_PK_NOP
+#undef wv
+#endif
+            }
+            return make_float4(a01.x, a01.y, a23.x, a23.y);
+        }
+#endif
 #pragma unroll 4
         for (int k = ch * per; k < k1; k += 4) {
             const float4 wv = w4[(size_t)(k >> 2) * width + col];
@@ -1702,7 +1744,7 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         return a;
     };
     const int nchP = 1024 / MEL, perP = ((2 * H + nchP - 1) / nchP + 3) / 4 * 4;
-    if (g < nchP * MEL) part[g] = partial(hs, wp, 2 * H, MEL, g % MEL, g / MEL, perP);
+    if (g < nchP * MEL) part[g] = partial(hs, wp, 2 * H, MEL, g % MEL, g / MEL, perP, 1);
     __syncthreads();
     if (g < MEL) {
         const float bb = bb_h;
@@ -1725,11 +1767,11 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
         return make_float4(v[0], v[1], v[2], v[3]);
     };
     const int nchN = 1024 / PN;
-    if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, ((MEL + nchN - 1) / nchN + 3) / 4 * 4);
+    if (g < nchN * PN) part[g] = partial(prev, f1, MEL, PN, g % PN, g / PN, ((MEL + nchN - 1) / nchN + 3) / 4 * 4, 2);
     __syncthreads();
     if (g < PN) p1[g] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 0, g);
     __syncthreads();
-    if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, ((PN + nchN - 1) / nchN + 3) / 4 * 4);
+    if (g < nchN * PN) part[g] = partial(p1, f2, PN, PN, g % PN, g / PN, ((PN + nchN - 1) / nchN + 3) / 4 * 4, 4);
     __syncthreads();
     if (g < PN) {
         const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);

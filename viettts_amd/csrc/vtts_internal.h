@@ -100,6 +100,13 @@ size_t conv_pre_x3_bytes();
 void conv_pre_x3_pack(const float* w_hk, unsigned short* out);
 hipError_t launch_conv_pre_x3(const ConvArgs& a, hipStream_t s);
 
+// ---- whole ResBlock1 with split operands (kernels_x3_rb.hip): three pairs + the MRF bookkeeping in one launch, bit-identical to three launch_pair_x3 ----
+// a = ConvArgs of the ResBlock (x = stage input [B][C][L], y = output with acc_mode / div, Cin = C, K, B, L, lens / len_mul, slope_in, zrev);
+// dils = the three rates; w[q] / bias[q] = the six convolutions (c1_0, c2_0, c1_1, ...), weights as pair_x3_pack lays them out
+bool resblock_x3_supported(int C, int K, const int* dils, int L);
+bool resblock_x3_preferred(int C, int K);
+hipError_t launch_resblock_x3(const ConvArgs& a, const int* dils, const void* const* w, const float* const* bias, hipStream_t s);
+
 // ---- fp32 polyphase transposed convolution on MFMA (k == 2*stride) -------------------------
 bool convT1d_f32_mfma_supported(int Cin, int Cout, int K, int stride, int pad_a, int L);
 size_t convT1d_f32_mfma_packed_floats(int Cin, int Cout, int K);
