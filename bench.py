@@ -326,6 +326,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="micro-batches in flight on separate HIP streams (0 = engine default)")
     ap.add_argument("--chains", type=int, default=-1, help="engine option 'chains' (0 / 1 / 2; -1 = engine default)")
     ap.add_argument("--fuse", type=int, default=-1, help="engine option 'fuse' (0..3; -1 = engine default)")
+    ap.add_argument("--tail", type=int, default=-1, help="engine option 'tail' (bf16: conv_post inside the last pair launch; 0 / 1; -1 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
@@ -362,6 +363,8 @@ def main():
         gen.set_option("chains", args.chains)
     if args.fuse >= 0:
         gen.set_option("fuse", args.fuse)
+    if args.tail >= 0:
+        gen.set_option("tail", args.tail)
     bstats = {}
     vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info, bstats)
 

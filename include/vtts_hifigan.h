@@ -41,7 +41,7 @@ typedef enum vtts_dtype {
     VTTS_BF16 = 1, /* bf16 operands, fp32 accumulate: v_mfma_f32_32x32x16_bf16                  */
     VTTS_BF16X3 = 2 /* the fp32 engine (fp32 activations in HBM, same layouts, same entry points) with the ResBlock convolutions — 96.8 % of
                        the FLOPs — on the bf16 matrix pipe with SPLIT operands: every product is three bf16 x bf16 terms (x1 w0 + x0 w1 + x0 w0,
-                       v = v0 + v1 the two-bf16-term split of an fp32 value), fp32 accumulate.  fp32-grade: whole-generator max-abs ~2e-5 against
+                       v = v0 + v1 the two-bf16-term split of an fp32 value), fp32 accumulate.  fp32-grade: whole-generator max-abs 1.6e-5 (measured: profiles/r05_*_bench.json, bf16x3_path.parity) against
                        the reference (5x inside BASELINE.json's 1e-4) at 3/16 of the fp32 MFMA time (kernels_x3.hip, profiles/r04_b_split_findings.md) */
 } vtts_dtype;
 
@@ -183,7 +183,10 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "kernels"   0 = auto (MFMA kernels where the shape allows, generic otherwise), 1 = generic only
  *   "microbatch" utterances processed per pass through the network (0 = auto)
  *   "fuse"      bf16: 2 = fused ResBlock pairs + the whole-ResBlock kernel of the C = 32 stage where it is the faster
- *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution
+ *               one (default), 3 = ... wherever it is supported, 1 = fused pairs only, 0 = one kernel per convolution;
+ *               bf16x3: 2 (default) = split-operand pairs + the whole-ResBlock kernel where it is faster (C = 32; C = 64 at k <= 7; C = 128 at k = 3),
+ *               3 = ... wherever it exists, 1 = pairs only, 0 = the fp32 engine's kernels; fp32: 1 = fused pairs at C <= 64, 2 (default) = + C = 128 at
+ *               k = 3, 3 = every pair the kernel covers
  *   "streams"   1..4: consecutive micro-batches run on separate HIP streams (forked from / joined to
  *               the caller's stream with events) so HBM phases of one overlap MFMA phases of another;
  *               0 (default) = the engine's choice: two streams, a large batch (more than 32768 frames) as equal micro-batches of at
@@ -198,6 +201,9 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *               and replayed from then on (about a millisecond once, then no host launch / event calls in the latency path: one 512-frame
  *               utterance 0.81 -> 0.69 ms bf16, 4.57 -> 3.65 ms fp32 together with "chains"); dropped when an option or the weight
  *               blob changes; inside a caller's own stream capture the launches are simply enqueued.  0 = always eager.
+ *   "tail"      VTTS_BF16: 1 (default) = the generator's last pair launch (stage 4, C = 32, k = 11) also runs conv_post + tanh on the rows it
+ *               produces — the stage output is never written and the streaming conv_post kernel is not launched; bit-identical samples;
+ *               0 = the separate kernel.  (forward_tap always takes the separate kernel: a tap wants the stage output.)
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
  *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
  *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.

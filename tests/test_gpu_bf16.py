@@ -277,6 +277,36 @@ def test_ragged_batch_equals_each_utterance_alone(fuse):
         gen.close()
 
 
+@pytest.mark.parametrize("tiles", [0, 1, 2])
+def test_stage4_tail_fusion_is_bit_identical(tiles):
+    """Option "tail" (default on, round 5): the generator's last pair launch (stage 4, k = 11) also runs conv_post + tanh (model.py:123-124) on its own
+    rows — the stage output is never written, conv_post_bf16_k is not launched.  The values conv_post sees and the order of its fmaf chain are the
+    un-fused path's, so the samples are BIT-IDENTICAL with the option off: plain batches (one frame ... several tiles), ragged batches, wide and narrow
+    tiles, the parallel-ResBlock schedule of small launches and the sequential one; a tap forces the un-fused path and still matches."""
+    from viettts_amd.hifigan.generator import Generator
+
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    gen.set_option("tiles", tiles)
+    try:
+        assert gen.get_option("tail") == 1
+        for B, T in ((1, 1), (2, 5), (3, 37), (2, 300), (9, 260)):
+            mel = torch.from_numpy(synthetic_mel(B, T, 70 + T)).to("cuda:0")
+            frames = [max(1, T - 3 * b) for b in range(B)]
+            gen.set_option("tail", 1)
+            fused, fused_r = gen(mel).clone(), gen.forward_ragged(mel, frames).clone()
+            tapped, pre = gen.forward_tap(mel, "pre_tanh")
+            gen.set_option("tail", 0)
+            plain, plain_r = gen(mel).clone(), gen.forward_ragged(mel, frames).clone()
+            assert torch.equal(fused, plain), (B, T)
+            assert torch.equal(fused_r, plain_r), (B, T)
+            assert torch.equal(tapped, plain) and torch.equal(torch.tanh(pre), plain) or float((torch.tanh(pre) - plain).abs().max()) < 1e-6
+            for b, n in enumerate(frames):
+                assert not bool(fused_r[b, 256 * n :].any())
+    finally:
+        gen.close()
+
+
 def test_ragged_batch_across_micro_batches_and_streams():
     """The engine splits a large batch into micro-batches (optionally on several streams); every micro-batch must see ITS
     utterances' lengths."""

@@ -178,3 +178,25 @@ def test_reference_haiku_generator_reproduces_the_committed_fixture(golden_dir):
     """) % (str(golden_dir.parents[1]), str(golden_dir / "tiny_scaled_T12.npz"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "same" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_parity_grade_fixture_is_what_the_oracle_gives(golden_dir):
+    """tests/golden/bench_parity_grade.npz (minted by oracle/make_bench_golden.py; read by bench.py's parity-grade legs, which must not import the
+    oracle): one long-form window re-minted here — the oracle generator on frames [lo - 13, hi + 13) of the 10-minute utterance's mel — equals the
+    fixture exactly, and the fixture's pipeline sentences carry consistent integer frame counts."""
+    import oracle.make_bench_golden as mk
+    from oracle.hifigan_oracle import generator_forward
+    from viettts_amd.hifigan.config import V1
+    from viettts_amd.hifigan.synth import synthetic_mel, synthetic_params
+
+    g = np.load(golden_dir / "bench_parity_grade.npz")
+    lo = int(g["lf_start_lo"])
+    assert lo == 0 and g["lf_start_wave"].shape == (256 * mk.WIN,)
+    mel = synthetic_mel(1, mk.T10, 99)
+    y = generator_forward(synthetic_params(V1, 4321, "scaled"), mel[:, : mk.WIN + mk.HALO], V1, np.float64)[0, :, 0]
+    assert np.array_equal(y[: 256 * mk.WIN], g["lf_start_wave"])
+    assert int(g["lf_seam_lo"]) == mk.CHUNK * 37 - mk.WIN // 2 and int(g["lf_end_lo"]) == mk.T10 - mk.WIN
+    for i in (int(v) for v in g["pipe_sentences"]):
+        nfr, trail = (int(v) for v in g[f"pipe_{i}_frames"])
+        assert g[f"pipe_{i}_wave"].shape == (256 * (nfr - trail),) and 0 <= trail < nfr
+        assert np.isfinite(g[f"pipe_{i}_wave"]).all() and float(np.abs(g[f"pipe_{i}_wave"]).max()) < 1.0

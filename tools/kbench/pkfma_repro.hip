@@ -113,7 +113,8 @@ __global__ __launch_bounds__(1024) void victim_k(const f32x2* __restrict__ w, in
     float r0 = 0.f, r1 = 0.f;
     unsigned lo = 0, hi = 0;
     for (int it = 0; it < iters; ++it) {
-        const f32x2* p = w + (size_t)(((g * 7 + it * 1031) % nw) & ~1);  // 16-byte aligned (the 16-byte variant)
+        // consecutive lanes read consecutive 16-byte units (a wave's load is 1 KiB contiguous, an L2 hit after the first pass: as the weights' loads in nat.hip)
+        const f32x2* p = w + (size_t)((((it * 3 + blockIdx.x) * 1024 + threadIdx.x) * 2) % nw);
         const f32x2 x = {0.5f + 0.001f * (it & 63), -0.25f + 0.002f * (threadIdx.x & 31)};
         f32x2 wv;
         // the load's destination is written by the VMEM return path; the packed FMA is the first instruction behind the wait

@@ -126,6 +126,7 @@ struct vtts_hifigan {
     uint64_t epoch = 0, use_clock = 0;  // epoch: bumped by everything a captured launch sequence bakes in (options, the weight blob)
     int64_t opt_zigzag = 1;          // consecutive launches walk the batch in alternating directions (see next_zrev)
     unsigned zrev_count = 0;
+    int64_t opt_tail = 1;            // bf16: conv_post + tanh inside the generator's last pair launch (0 = the separate streaming kernel)
     int64_t opt_chains = 1;          // small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other, 2 = always)
     hipEvent_t ev_chain[3] = {nullptr, nullptr, nullptr};  // bf16: ResBlock j's output is in the shared accumulator (orders the accumulating epilogues)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
@@ -690,7 +691,7 @@ int run_layer_bf16(vtts_hifigan* h, const Layer& l, const void* x, int x_pitch, 
 }
 
 int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L, float slope_out, void* y, int acc_add, float div,
-                  hipStream_t s) {
+                  hipStream_t s, float* tail_wav = nullptr) {
     BConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x;
@@ -710,6 +711,12 @@ int run_pair_bf16(vtts_hifigan* h, const Layer& c1, const void* x, int B, int L,
     a.div = div;
     a.tile_pref = (int)h->opt_tiles;
     a.zrev = next_zrev(h);
+    if (tail_wav) {  // the stage-4 tail rides on this launch: conv_post + tanh from the rows this pair produces (kernels_bf16_rbg.hip: GTail)
+        const Layer& post = h->layers[h->idx_post];
+        a.tail_wav = tail_wav;
+        a.tail_wf = reinterpret_cast<const float*>(h->blob + post.off_w);
+        a.tail_bias = reinterpret_cast<const float*>(h->blob + post.off_b);
+    }
     const bool prof = h->opt_profile && c1.cin == h->prof_C && c1.k == h->prof_K;
     if (prof) {
         if (h->prof_used == h->prof_events.size()) {
@@ -932,6 +939,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
             }
         }
         long L = T;
+        bool tail_done = false;  // conv_post + tanh already ran inside the last pair launch
         for (int i = 0; i < c.num_upsamples; ++i) {
             const Layer& up = h->layers[h->idx_ups[i]];
             rc = run_layer_bf16(h, up, bufS, up.cin, up.cin, nb, (int)L, 1.0f, 1.0f, nullptr, bufX, 0, 1.f, s);
@@ -944,6 +952,20 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 if (rc) return rc;
             }
             const float next_slope = (i + 1 < c.num_upsamples) ? 0.1f : 0.01f;  // model.py:112 / :122
+            // the stage-4 tail (option "tail", default on): the generator's last pair launch also runs conv_post + tanh on its own rows, so the stage
+            // output is never written and conv_post_bf16_k is not launched.  Where the last ResBlock ends in a pair launch that can carry it (V1: C = 32,
+            // k = 11) and nothing needs the stage output itself (no tap)
+            float* tail_dst = nullptr;
+            if (h->opt_tail && !tap.name && i + 1 == c.num_upsamples && c.resblock != 2 && h->opt_fuse >= 1) {
+                const int lb = h->idx_res[i * nk + nk - 1];
+                const Layer& lc = h->layers[lb];
+                const Layer& post = h->layers[h->idx_post];
+                const bool whole_rb = h->opt_fuse >= 2 && lc.has_rb && (h->opt_fuse >= 3 || resblock_bf16_preferred(lc.cin, lc.k));
+                if (!whole_rb && lc.has_pair && h->layers[lb + 2].has_pair && h->layers[lb + 4].has_pair &&
+                    pair_tail_bf16_supported(lc.cin, lc.k, post.cin, post.cout, post.k))
+                    tail_dst = wav + (size_t)b0 * wav_len;
+            }
+            tail_done = tail_dst != nullptr;
             // one ResBlock of the MRF: X -> (tT, tC scratch) -> the shared accumulator S (store / accumulate / accumulate-and-divide in the
             // LAST kernel's epilogue); `before_last` runs right before that kernel is enqueued (the parallel schedule's ordering point)
             auto run_chain = [&](int j, char* tT, char* tC, hipStream_t cs, auto before_last) -> int {
@@ -973,7 +995,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                     if ((rcc = run_pair_bf16(h, h->layers[base + 2], tT, nb, (int)L, 1.0f, tC, 0, 1.f, cs))) return rcc;
                     if ((rcc = before_last())) return rcc;
                     return run_pair_bf16(h, h->layers[base + 4], tC, nb, (int)L, last_rb ? next_slope : 1.0f, bufS, j > 0 ? 1 : 0,
-                                         last_rb ? (float)nk : 1.0f, cs);
+                                         last_rb ? (float)nk : 1.0f, cs, last_rb ? tail_dst : nullptr);
                 }
                 for (int z = 0; z < 3; ++z) {
                     const Layer& c1 = h->layers[base + 2 * z];
@@ -1027,7 +1049,7 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 if (rc) return rc;
             }
         }
-        {
+        if (!tail_done) {
             const Layer& l = h->layers[h->idx_post];
             BConvArgs a;
             memset(&a, 0, sizeof(a));
@@ -1667,7 +1689,7 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
     {  // setting a WRITABLE option to the value it has changes nothing: captured graphs stay valid (read-only and unknown names fall through to their errors)
-        static const char* const writable[] = {"kernels", "microbatch", "fuse", "streams", "graph", "zigzag", "chains", "tiles"};
+        static const char* const writable[] = {"kernels", "microbatch", "fuse", "streams", "graph", "zigzag", "chains", "tiles", "tail"};
         for (const char* w : writable) {
             int64_t cur = 0;
             if (!strcmp(name, w) && vtts_hifigan_get_option(h, name, &cur) == VTTS_OK && cur == value) return VTTS_OK;
@@ -1698,6 +1720,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "tiles")) {
         if (value < 0 || value > 2) return fail(VTTS_ERR_INVALID, "tiles must be 0 (auto), 1 (wide) or 2 (narrow)");
         h->opt_tiles = value;
+    } else if (!strcmp(name, "tail")) {
+        if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "tail must be 0 or 1");
+        h->opt_tail = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
     } else if (!strcmp(name, "hop") || !strcmp(name, "pass_frames") || !strcmp(name, "max_frames_per_pass") || !strcmp(name, "graphs_cached") ||
@@ -1719,6 +1744,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "zigzag")) *value = h->opt_zigzag;
     else if (!strcmp(name, "chains")) *value = h->opt_chains;
     else if (!strcmp(name, "graph")) *value = h->opt_graph;
+    else if (!strcmp(name, "tail")) *value = h->opt_tail;
     else if (!strcmp(name, "graphs_cached")) {
         *value = 0;
         for (auto& g : h->graphs) *value += g.exec ? 1 : 0;

@@ -95,9 +95,29 @@ struct GTile {
         const int bx = tile_rows16(N1 + 2 * H2 * dil) * P1, bt = tile_rows16(ROWST) * P2;
         return bx > bt ? bx : bt;
     }
+    // TAIL (GTail below): the generator's tail — conv_post (32 -> 1, k = 7) + tanh — run by this kernel on its own output rows (stage 4's last pair)
+    static constexpr bool TAIL = false;
+    static constexpr int TAIL_KS = 7, TAIL_H = 3;
+    static constexpr int TAIL_BYTES = 0;
     static int lds_bytes(int dil) { return tile_bytes(dil) + RAW_BYTES; }
     static_assert(tile_rows16(ROWSX_MAX) * P1 + RAW_BYTES <= 80 * 1024 || !RAWRES, "two workgroups per CU");
     static_assert(tile_rows16(ROWSX_MAX) * P1 <= 160 * 1024 && tile_rows16(ROWST) * P2 <= 160 * 1024, "LDS budget");
+};
+
+// The stage-4 tail (round 5; asked for since round 2): the LAST pair launch of the generator's last stage — the one whose epilogue already forms the MRF
+// mean and applies the tail's LeakyReLU(0.01) (model.py:121-122) — keeps its bf16 output rows in LDS (in place of the raw residual rows it has just
+// consumed there), and after one barrier computes conv_post + tanh (model.py:123-124) from them: the stage output (1.07 GB at 64 x 1024 frames) is never
+// written, conv_post_bf16_k's launch and its re-read are gone.  A tile then yields NT2 - 6 samples (conv_post's halo of 3 per side comes out of the tile's
+// own rows: its stride shrinks by 6 and tile 0 starts at time -3, whose rows are the reference's zero padding).  The values conv_post sees are the bf16 values
+// the un-fused path stores, its fmaf chain runs in conv_post_bf16_k's order (tap-major, channels ascending): bit-identical samples
+// (tests/test_gpu_bf16.py::test_stage4_tail_fusion_is_bit_identical).
+template <class B>
+struct GTail : B {
+    static constexpr bool TAIL = true;
+    static constexpr int TAIL_BYTES = 1024;  // conv_post's 7 x 32 fp32 weights behind the residual region
+    static int lds_bytes(int dil) { return B::tile_bytes(dil) + B::RAW_BYTES + TAIL_BYTES; }
+    static_assert(B::RAWRES && B::C == 32 && B::WM == 1, "the tail lives on the C = 32 tile with the LDS-resident residual rows");
+    static_assert(B::tile_bytes(B::MAXDIL) + B::RAW_BYTES + TAIL_BYTES <= 80 * 1024, "two workgroups per CU");
 };
 
 template <class T>
@@ -131,15 +151,17 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
     // Only launches whose utterance slots hold at least XCD_MAP_MIN_TILES tiles do this (the launcher pads gridDim.x for exactly those):
     // with a few tiles per eighth the saving is small, and a padded grid sends tile t of EVERY utterance to XCD t % 8, which on the
     // 256-sentence pipeline (15-140 tiles per utterance and stage) left the last XCDs a tile short per utterance: 2-4 % slower.
-    const bool xmap = (a.L + NT2 - 1) / NT2 >= XCD_MAP_MIN_TILES;
-    const int nt = (L + NT2 - 1) / NT2, r = (int)((blockIdx.x + b) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
+    constexpr int TS = T::TAIL ? NT2 - 2 * T::TAIL_H : NT2;  // tile stride (TAIL: conv_post's halo comes out of the tile's own rows)
+    const bool xmap = (a.L + TS - 1) / TS >= XCD_MAP_MIN_TILES;
+    const int nt = (L + TS - 1) / TS, r = (int)((blockIdx.x + b) & 7), lo = (r * nt) >> 3, hi = ((r + 1) * nt) >> 3;
     const int tile = xmap ? lo + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (xmap && tile >= hi) return;
 #else
+    constexpr int TS = T::TAIL ? NT2 - 2 * T::TAIL_H : NT2;
     const int tile = blockIdx.x;
 #endif
-    const int t0 = tile * NT2;               // first output time step of this workgroup
-    if (t0 >= L) return;                                     // a tile past this utterance's end: nothing reads its rows
+    const int t0 = tile * TS - (T::TAIL ? T::TAIL_H : 0);   // first output time step (row 0 of c2's output) of this workgroup
+    if (t0 + (T::TAIL ? T::TAIL_H : 0) >= L) return;        // a tile past this utterance's end: nothing reads its rows
     const int dil = a.dil;
     const int h1 = H2 * dil;                 // c1's symmetric pad (model.py:8-10)
     const int rowsx = N1 + 2 * h1;           // X rows: times t0 - H2 - h1 ... t0 - H2 - h1 + rowsx - 1
@@ -167,6 +189,10 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
         }
     };
     load_bias(a.bias);
+    if constexpr (T::TAIL) {  // conv_post's weights (Haiku [K][Cin][1] fp32) behind the residual region; visible after the staging barrier
+        float* tw = reinterpret_cast<float*>(lds + T::tile_bytes(dil) + T::RAW_BYTES);
+        for (int i = tid; i < T::TAIL_KS * C; i += THREADS) tw[i] = a.tail_wf[i];
+    }
 
     // ---------------- C = 32: register-resident weights ----------------
     // What the per-workgroup timelines show at C = 32 (tools/kbench, gpurun_out/r03_exp8/timeline.txt): the loops take 11.4k + 7.5k
@@ -523,7 +549,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
 #pragma unroll
                     for (int nr = 0; nr < NR; ++nr) {
                         const int t = t0 + wn * (N1 / WN) + nr * 32 + l31;
-                        const int tc = t < L ? t : L - 1;  // rows past the end are never stored: any in-bounds address will do
+                        const int tc = t < 0 ? 0 : (t < L ? t : L - 1);  // rows outside the utterance are never stored: any in-bounds address will do
                         rv[mr][p][nr] = *reinterpret_cast<const uint4*>(src + (size_t)tc * C + wm * (C / T::WM) + mr * 32 + 16 * p + 8 * lh);
                     }
 #if VTTS_TIMELINE
@@ -578,7 +604,7 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                 for (int nr = 0; nr < NR; ++nr) {
                     const int row = wn * (N1 / WN) + nr * 32 + l31;
                     const int t = t0 + row;
-                    const bool ok = row < NT2 && t < L;
+                    const bool ok = row < NT2 && t >= 0 && t < L;
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = acc[mr][nr][8 * p + e];
@@ -594,9 +620,40 @@ __global__ __launch_bounds__(T::THREADS, (T::MINWG * T::THREADS + 255) / 256) vo
                     unsigned q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
                     swap_pair(p0, q0);
                     swap_pair(p1, q1);
-                    if (ok) *reinterpret_cast<uint4*>(yg + (size_t)t * C + cb + 8 * lh) = make_uint4(p0, p1, q0, q1);
+                    if constexpr (T::TAIL) {
+                        // the row stays in LDS, where this lane has just read its residual values (same row, same slot: no other lane touches it);
+                        // rows outside the utterance are conv_post's zero padding
+                        const uint4 o = ok ? make_uint4(p0, p1, q0, q1) : make_uint4(0u, 0u, 0u, 0u);
+                        if (row < NT2) *reinterpret_cast<uint4*>(xraw + tile_off<SPR1>(row, (cb >> 3) + lh)) = o;
+                    } else {
+                        if (ok) *reinterpret_cast<uint4*>(yg + (size_t)t * C + cb + 8 * lh) = make_uint4(p0, p1, q0, q1);
+                    }
                 }
             }
+        }
+    }
+    if constexpr (T::TAIL) {
+        // ---------------- tail: tanh(conv_post(.)) over the rows just written (model.py:123-124); conv_post_bf16_k's arithmetic, in its order ----------------
+        __syncthreads();
+        const float* tw = reinterpret_cast<const float*>(lds + T::tile_bytes(dil) + T::RAW_BYTES);
+        const float tb = a.tail_bias[0];
+        for (int n = tid; n < TS; n += THREADS) {
+            const int t = t0 + T::TAIL_H + n;  // output sample: reads rows n .. n + 6 = times t - 3 .. t + 3
+            if (t >= L) break;
+            float accp = 0.f;
+#pragma unroll
+            for (int j = 0; j < T::TAIL_KS; ++j) {
+#pragma unroll
+                for (int c = 0; c < SPR1; ++c) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(xraw + tile_off<SPR1>(n + j, c));
+                    const float* w = tw + j * C + c * 8;
+                    accp = fmaf(w[0], bf16_lo(v.x), accp); accp = fmaf(w[1], bf16_hi(v.x), accp);
+                    accp = fmaf(w[2], bf16_lo(v.y), accp); accp = fmaf(w[3], bf16_hi(v.y), accp);
+                    accp = fmaf(w[4], bf16_lo(v.z), accp); accp = fmaf(w[5], bf16_hi(v.z), accp);
+                    accp = fmaf(w[6], bf16_lo(v.w), accp); accp = fmaf(w[7], bf16_hi(v.w), accp);
+                }
+            }
+            a.tail_wav[(size_t)b * Lp + t] = tanhf(accp + tb);
         }
     }
     VTTS_TL(a, wg_lin, 6);
@@ -639,7 +696,8 @@ static hipError_t launch_g(const BConvArgs& a, hipStream_t s) {
     static DynLdsOnce once;  // per device (vtts_internal.h)
     if (hipError_t e = set_max_dynamic_lds(reinterpret_cast<const void*>(&resblock_pair_g_bf16_k<T>), T::lds_bytes(T::MAXDIL) + VTTS_EXP_LDS_PAD, once); e != hipSuccess) return e;
     if (a.dil < 1 || a.dil > T::MAXDIL) return hipErrorInvalidValue;
-    dim3 grid((a.L + T::NT2 - 1) / T::NT2, 1, a.B);
+    constexpr int TS = T::TAIL ? T::NT2 - 2 * T::TAIL_H : T::NT2;
+    dim3 grid((a.L + TS - 1) / TS, 1, a.B);
 #if VTTS_XCD_MAP
     if ((int)grid.x >= XCD_MAP_MIN_TILES) grid.x = (grid.x + 7) / 8 * 8;  // whole rounds of the 8 XCDs; a tile index past the utterance exits at once
 #endif
@@ -664,10 +722,18 @@ hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s) {
         case 256: return narrow(G256<11>::NT2) ? launch_g_ks<G256S>(a, K, s) : launch_g_ks<G256>(a, K, s);
         case 128: return narrow(G128<11>::NT2) ? launch_g_ks<G128S>(a, K, s) : launch_g_ks<G128>(a, K, s);
         case 64: return narrow(G64<11>::NT2) ? launch_g_ks<G64S>(a, K, s) : launch_g_ks<G64>(a, K, s);
-        case 32: return narrow(G32<11>::NT2) ? launch_g_ks<G32S>(a, K, s) : launch_g_ks<G32>(a, K, s);
+        case 32:
+            if (a.tail_wav) {  // the stage-4 tail rides on this launch (engine.hip: only where pair_tail_bf16_supported)
+                if (K != 11) return hipErrorInvalidValue;
+                return narrow(G32<11>::NT2) ? launch_g<GTail<G32S<11>>>(a, s) : launch_g<GTail<G32<11>>>(a, s);
+            }
+            return narrow(G32<11>::NT2) ? launch_g_ks<G32S>(a, K, s) : launch_g_ks<G32>(a, K, s);
     }
     return hipErrorInvalidValue;
 }
+
+// where the last pair of the last stage can carry conv_post + tanh: C = 32 pairs at k = 11 (the V1 generator's last ResBlock), conv_post 32 -> 1, k = 7
+bool pair_tail_bf16_supported(int C, int K, int post_cin, int post_cout, int post_k) { return C == 32 && K == 11 && post_cin == 32 && post_cout == 1 && post_k == 7; }
 
 // one convolution = [q = tap*KSTEPS + ks][mblk][lane][8] bf16: bf16_pack with (ckc = C, tg = 1, mt = C)
 BPackGeom pair_g_pack_geom(int C, int K) { return BPackGeom{C, C, C, K, C, 1}; }

@@ -144,6 +144,11 @@ struct BConvArgs {
     float div;            // then the MRF mean v / div as v * (1 / div) (bf16_common.h: mrf_recip), 1 = none
     int zrev;             // 1 = utterance = gridDim.z - 1 - blockIdx.z: the launch walks the batch backwards (engine.hip: next_zrev)
     unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE): per-workgroup s_memtime stamps; else unused
+    // stage-4 tail fused into the last pair launch (kernels_bf16_rbg.hip: GTail): conv_post's plain fp32 weights [7][32] and bias, the waveform
+    // [B][L] fp32 (pitch = this layer's L); nullptr = a plain pair launch
+    float* tail_wav;
+    const float* tail_wf;
+    const float* tail_bias;
 };
 
 struct BPackGeom { int cinp, ckc, coutp, ks, mt, tg; };
@@ -158,6 +163,7 @@ void bf16_pack(const float* Wc, int cin_real, const BPackGeom& g, unsigned short
 bool pair_bf16_supported(int C, int K, int dil);
 BPackGeom pair_pack_geom(int C, int K);
 hipError_t launch_pair_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
+bool pair_tail_bf16_supported(int C, int K, int post_cin, int post_cout, int post_k);
 const char* pair_kernel_name(int C, int K);
 // kernels_bf16_rbg.hip: weights straight from L2 into register rings, no workgroup sync in the main loops
 hipError_t launch_pair_g_bf16(int C, int K, const BConvArgs& a, hipStream_t s);

@@ -214,15 +214,21 @@ class AcousticModel:
         if B == 0 or min(lens) < 1 or min(n_frames) < 1:
             raise ValueError("empty batch, token sequence or frame count")
         Lmax, Fmax = max(lens), int(max(n_frames))
+        # every argument check before anything is uploaded or grown
+        if group_row0 is not None and to_host:
+            raise ValueError("group_row0 hands the mel over on the device: use to_host=False")
+        if dropout_seeds is not None and keep_masks is None and dropout_rng is None and len(dropout_seeds) != B:
+            raise ValueError("one dropout seed per sentence")
         if encoded is not None:
             if encoded.dim() != 3 or encoded.shape[0] != B or encoded.shape[1] < Lmax or encoded.shape[2] != 2 * self.encoder_dim or encoded.dtype != torch.float32:
                 raise ValueError(f"encoded must be float32 [{B}, >= {Lmax}, {2 * self.encoder_dim}] (got {tuple(encoded.shape)} {encoded.dtype})")
             encoded = encoded.contiguous()
             Lmax = int(encoded.shape[1])
-        tok = np.zeros((B, Lmax), dtype=np.int32)
+        tok = np.zeros((B, Lmax), dtype=np.int32) if encoded is None else None  # (the C side ignores the tokens when the encoder's output is given)
         dur = np.zeros((B, Lmax), dtype=np.float32)
         for i, s in enumerate(sentences):
-            tok[i, : lens[i]] = np.asarray(s, dtype=np.int32)
+            if tok is not None:
+                tok[i, : lens[i]] = np.asarray(s, dtype=np.int32)
             dur[i, : lens[i]] = np.asarray(durations_frames[i], dtype=np.float32).reshape(-1)
         keep_d = None
         if keep_masks is not None:
@@ -233,10 +239,8 @@ class AcousticModel:
         elif dropout_rng is not None:
             keep_d = self.device_keep_masks_haiku(dropout_rng, B, Fmax)
         elif dropout_seeds is not None:
-            if len(dropout_seeds) != B:
-                raise ValueError("one dropout seed per sentence")
             keep_d = self.device_keep_masks(dropout_seeds, Fmax)
-        tok_d = torch.from_numpy(tok).to(self.device)
+        tok_d = torch.from_numpy(tok).to(self.device) if tok is not None else None
         dur_d = torch.from_numpy(dur).to(self.device)
         len_d = torch.tensor(lens, dtype=torch.int32, device=self.device)
         nf_d = torch.tensor([int(n) for n in n_frames], dtype=torch.int32, device=self.device)
@@ -247,8 +251,6 @@ class AcousticModel:
             self._ws = torch.empty(int(n.value), dtype=torch.uint8, device=self.device)
         stream = torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
-            if group_row0 is not None and to_host:
-                raise ValueError("group_row0 hands the mel over on the device: use to_host=False")
             if encoded is not None:
                 r0 = [int(v) for v in group_row0] if group_row0 is not None else [0]
                 ng = len(r0) - 1
