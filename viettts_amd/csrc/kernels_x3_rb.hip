@@ -116,6 +116,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
             for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int tw = t0 - M;     // time of window row 0
+    const bool interior = tw >= 0 && tw + W <= L;  // every row of the window lies inside the utterance: no clamps, no zero-padding masks (workgroup-uniform)
     RX_TL(0);
     if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 24 + 23] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     const float* __restrict__ xb = a.x + (long)b * C * LP;
@@ -140,19 +141,28 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
     float xr[MR][NR][16];
     // (A 16-byte form of these loads — rows through an fp32 transposition area in LDS, as the stores at the kernel's end — measured SLOWER: two more
     //  barriers and an LDS round trip in front of the first MFMA, 10k -> 25k cycles of a 76k-cycle window at k = 3; gpurun_out/r05_x3ab4.)
+    if (interior) {
 #pragma unroll
-    for (int mr = 0; mr < MR; ++mr)
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-        for (int nr = 0; nr < NR; ++nr) {
-            const int t = tw + col0 + nr * 32;
-            const bool ok = t >= 0 && t < L;
-            const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+            for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = xb[(long)(cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tc];
-                xr[mr][nr][r] = ok ? v : 0.0f;
+                for (int r = 0; r < 16; ++r) xr[mr][nr][r] = xb[(long)(cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tw + col0 + nr * 32];
+    } else {
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                const int t = tw + col0 + nr * 32;
+                const bool ok = t >= 0 && t < L;
+                const int tc = t < 0 ? 0 : (t >= L ? L - 1 : t);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = xb[(long)(cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LP + tc];
+                    xr[mr][nr][r] = ok ? v : 0.0f;
+                }
             }
-        }
+    }
     // ---- guard rows of both planes = 0 (never written again) ----
     for (int u = tid; u < 2 * GUARD * SPR; u += THREADS) {
         const int gr = u % (2 * GUARD), c = u / (2 * GUARD);
@@ -278,7 +288,6 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
         }
     };
 
-    const bool interior = tw >= 0 && tw + W <= L;  // every row of the window lies inside the utterance: no zero-padding masks (workgroup-uniform)
     // ---- stage the tile = lrelu(x) from the residual registers (zero outside the utterance: xr is) ----
 #pragma unroll
     for (int mr = 0; mr < MR; ++mr)
@@ -312,13 +321,15 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
             for (int r = 0; r < 16; ++r) bv[r] = b1[cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
-                const int t = tw + col0 + nr * 32;
-                const bool ok = interior || (t >= 0 && t < L);
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] = lrelu_f(acc[mr][nr][r] + bv[r], slope);  // max(v, slope v): the compare-and-select form's value for every finite v (bf16_common.h)
-                    if (!ok) v[r] = 0.0f;
+                for (int r = 0; r < 16; ++r) v[r] = lrelu_f(acc[mr][nr][r] + bv[r], slope);  // max(v, slope v): the compare-and-select form's value for every finite v (bf16_common.h)
+                if (!interior) {  // (workgroup-uniform branch: all but an utterance's first and last windows skip the 16 v_cndmask per block — 19 cycles each alone, profiles/r03_a_coissue_findings.md)
+                    const int t = tw + col0 + nr * 32;
+                    const bool ok = t >= 0 && t < L;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (!ok) v[r] = 0.0f;
                 }
                 write_tile(aHi, aLo, mr, nr, v);
             }
@@ -351,13 +362,15 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
             for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
                 for (int nr = 0; nr < NR; ++nr) {
-                    const int t = tw + col0 + nr * 32;
-                    const bool ok = interior || (t >= 0 && t < L);
                     float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        v[r] = lrelu_f(xr[mr][nr][r], slope);
-                        if (!ok) v[r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) v[r] = lrelu_f(xr[mr][nr][r], slope);
+                    if (!interior) {
+                        const int t = tw + col0 + nr * 32;
+                        const bool ok = t >= 0 && t < L;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (!ok) v[r] = 0.0f;
                     }
                     write_tile(aHi, aLo, mr, nr, v);
                 }
