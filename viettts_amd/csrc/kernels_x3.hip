@@ -145,13 +145,17 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
     };
 
     f32x16 acc[MR][NR];
-    auto zero_acc = [&]() {
+    // the accumulators start from the bias (round 5: the same values resblock_x3_k's first MFMA takes as its C operand — kernels_x3_rb.hip — so the two
+    // kernels stay bit-identical; the epilogues add no bias)
+    auto init_acc = [&](const float* __restrict__ bias) {
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
+            for (int r = 0; r < 16; ++r) {
+                const float bv = bias[m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
+                for (int nr = 0; nr < NR; ++nr) acc[mr][nr][r] = bv;
+            }
     };
 
     // ---- one convolution pass over the LDS tiles: acc += W[:, chunk] (*) tile, three bf16 products per operand pair ----
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
     };
 
     // ---------------- phase 1: xt = c1(lrelu(x)); column n <-> time t0 - H2 + n; tap j reads X row n + j*dil ----------------
-    zero_acc();
+    init_acc(a.bias);
 #pragma unroll
     for (int xc = 0; xc < NXC; ++xc) {
         if (xc > 0) __syncthreads();  // every wave is done reading the previous channel chunk
@@ -254,9 +258,6 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             const int cb = m0 + mr * 32 + 16 * pp;
-            float bv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bv[e] = a.bias[cb + 8 * (e >> 2) + 4 * lh + (e & 3)];
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 const int row = wn * (N1 / WN) + nr * 32 + l31;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    v[e] = lrelu(acc[mr][nr][8 * pp + e] + bv[e], slope);
+                    v[e] = lrelu(acc[mr][nr][8 * pp + e], slope);  // (b1 is in the sum already)
                     if (!ok) v[e] = 0.0f;  // c2's own zero padding applies to xt
                 }
                 unsigned hp0, hp1, hq0, hq1, lp0, lp1, lq0, lq1;
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
         *reinterpret_cast<uint4*>(thi + off) = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(tlo + off) = make_uint4(0u, 0u, 0u, 0u);
     }
-    zero_acc();
+    init_acc(p.bias2);
     __syncthreads();  // xt tiles written
 
     // ---------------- phase 2: c2 over the xt tiles (rate 1): column n <-> time t0 + n, tap j reads xt row n + j ----------------
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_pair_x3_k(PairArg
                 for (int q = 0; q < 8; ++q) {
                     const int r = r0 + q;
                     const int co = m0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    float v = acc[mr][nr][r] + p.bias2[co];
+                    float v = acc[mr][nr][r];  // (b2 is in the sum already)
                     v = v + rres[nr][r];
                     if (mode == ACC_ADD) v = yv[q] + v;
                     else if (mode == ACC_MEAN) v = (yv[q] + v) / dv;

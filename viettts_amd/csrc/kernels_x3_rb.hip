@@ -74,11 +74,14 @@ struct RXTile {
     static constexpr int PA = 1, RA = PA + 1;              // A-fragment ring: k-steps ahead / slots
     static constexpr int PLANE = tile_rows16(ROWS) * P;
     static constexpr int FS = W + 4;                       // row stride (floats) of the fp32 transposition area [C][FS] that shares the planes' LDS at both ends of the kernel
-    static constexpr int LDS_BYTES = 2 * PLANE > C * FS * 4 ? 2 * PLANE : C * FS * 4;
+    static constexpr int AREA_BYTES = 2 * PLANE > C * FS * 4 ? 2 * PLANE : C * FS * 4;  // the planes, or the transposition area
+    static constexpr int BIAS_BYTES = 6 * C * 4;            // the six convolutions' biases, staged once behind the planes (16 per-lane global loads per epilogue
+                                                            // were a vector-memory instruction apiece, on the port the partner workgroup's MFMAs starve)
+    static constexpr int LDS_BYTES = AREA_BYTES + BIAS_BYTES;
     static constexpr size_t CONV_BYTES = (size_t)KS * C * C * 2;  // one plane (hi or lo) of one convolution
     static_assert(C % (WM * 32) == 0 && W % (WN * 32) == 0 && W % 64 == 0, "window / wave tiling");
     static_assert(KSTEPS % RA == 0 && KSTEPS % 2 == 0 && KSX1 % RA == 0 && KSX1 % 2 == 0 && KSTEPS % KSX1 == 0, "ring slot / B parity are compile-time positions in a tap");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES <= 160 * 1024 && 2 * LDS_BYTES <= 160 * 1024, "LDS budget: two workgroups per CU");
 };
 
 template <class T>
@@ -121,6 +124,8 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
     if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 24 + 23] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     const float* __restrict__ xb = a.x + (long)b * C * LP;
     float* yb = a.y + (long)b * C * LP;
+    float* const sbias = reinterpret_cast<float*>(lds + T::AREA_BYTES);  // [6][C]; written here, read from epilogue 1 of pair 0 on (two barriers later)
+    for (int u = tid; u < 6 * C; u += THREADS) sbias[u] = p.bias[u / C][u % C];
     const int cb0 = wm * (C / T::WM);  // this wave's first output channel
     const float slope = a.slope_in;    // LRELU_SLOPE, both activations of every pair (model.py:46,48)
 
@@ -174,14 +179,6 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
     }
 
     f32x16 acc[MR][NR];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mr = 0; mr < MR; ++mr)
-#pragma unroll
-            for (int nr = 0; nr < NR; ++nr)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mr][nr][r] = 0.0f;
-    };
 
     // ---- one convolution over a tile pair: acc += W (*) tile, centred taps: output column n reads tile row GUARD + n + (tap - H) * dl ----
     // A fragment (plane, tap, ks, mr): 16 bytes per lane at  w + plane * CONV_BYTES + (((tap * KSTEPS + ks) * MB + wm * MR + mr) * 64 + lane) * 16
@@ -203,8 +200,22 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
 #pragma unroll
     for (int s = 0; s < PA; ++s) load_a_from(p.w[0], s, s % RA);  // the stream's first fragments, under the loads of x
 
-    auto conv_phase = [&](auto nks_tag, const void* __restrict__ w, const void* __restrict__ wnext, int dl, const unsigned char* __restrict__ thi, const unsigned char* __restrict__ tlo) {
+    // The accumulators START FROM THE BIAS: the very first MFMA of every 32 x 32 block takes a 16-register bias block (read from the LDS copy) as its C
+    // operand — no accumulator initialisation (64 v_mov per convolution and wave) and no bias add in the epilogues (64 more), on a kernel whose epilogues
+    // are VALU-bound.  resblock_pair_x3_k starts its accumulators from the same values (kernels_x3.hip: init_acc), so the two stay bit-identical.
+    auto conv_phase = [&](auto nks_tag, const float* __restrict__ bias_lds, const void* __restrict__ w, const void* __restrict__ wnext, int dl, const unsigned char* __restrict__ thi, const unsigned char* __restrict__ tlo) {
         constexpr int NKS = decltype(nks_tag)::value;  // k-steps per channel chunk: flat step s = (chunk * KS + tap) * NKS + i  <->  k-step chunk * NKS + i of tap `tap`
+        f32x16 bblk[MR];
+#pragma unroll
+        for (int mr = 0; mr < MR; ++mr)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias_lds + cb0 + mr * 32 + 8 * rq + 4 * lh);
+                bblk[mr][4 * rq + 0] = bv.x;
+                bblk[mr][4 * rq + 1] = bv.y;
+                bblk[mr][4 * rq + 2] = bv.z;
+                bblk[mr][4 * rq + 3] = bv.w;
+            }
         const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, (int)(2 * T::CONV_BYTES), 0x00020000);
         const auto rs_n = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(wnext ? wnext : w), 0, (int)(2 * T::CONV_BYTES), 0x00020000);
         bf16x8 bf[2][NR][2];
@@ -231,8 +242,8 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
             }
         };
         load_b(0, 0);  // (the first PA A fragments are already in the ring)
-#pragma unroll 1
-        for (int s0 = 0; s0 < NSTEPS; s0 += NKS) {  // one (chunk, tap) per iteration
+        auto tap_iter = [&](int s0, auto first_tag) {  // one (chunk, tap): NKS k-steps; first_tag: the phase's very first step (C operand = the bias block)
+            constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
             for (int i = 0; i < NKS; ++i) {
                 load_a(s0 + i + PA, (i + PA) % RA);
@@ -242,7 +253,8 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
-                    for (int nr = 0; nr < NR; ++nr) acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][1], bf[par][nr][0], acc[mr][nr], 0, 0, 0);
+                    for (int nr = 0; nr < NR; ++nr)
+                        acc[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[sl][mr][1], bf[par][nr][0], (FIRST && i == 0) ? bblk[mr] : acc[mr][nr], 0, 0, 0);
 #pragma unroll
                 for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
@@ -264,7 +276,10 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
                     }
                 }
             }
-        }
+        };
+        tap_iter(0, std::true_type{});
+#pragma unroll 1
+        for (int s0 = NKS; s0 < NSTEPS; s0 += NKS) tap_iter(s0, std::false_type{});
     };
 
     // this lane's 16 values of block (mr, nr), already biased / activated / masked by the caller -> split -> tile rows (8 consecutive channels per
@@ -305,25 +320,21 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
 #pragma unroll 1
     for (int pr = 0; pr < 3; ++pr) {
         const int dl = pr == 0 ? d0 : (pr == 1 ? d1 : d2);
-        const float* __restrict__ b1 = p.bias[2 * pr];
-        const float* __restrict__ b2 = p.bias[2 * pr + 1];
+        const float* const b1 = sbias + (2 * pr) * C;
+        const float* const b2 = sbias + (2 * pr + 1) * C;
         // ---- c1 over the tile ----
-        zero_acc();
-        conv_phase(std::integral_constant<int, T::KSX1>{}, p.w[2 * pr], p.w[2 * pr + 1], dl, aHi, aLo);
+        conv_phase(std::integral_constant<int, T::KSX1>{}, b1, p.w[2 * pr], p.w[2 * pr + 1], dl, aHi, aLo);
         RX_TL(3 + 6 * pr);
         __syncthreads();  // every wave is done reading lrelu(x)
         RX_TL(4 + 6 * pr);
         // ---- xt = lrelu(c1 + b1), zero outside [0, L) (c2's own zero padding applies to xt) -> the tile ----
 #pragma unroll
         for (int mr = 0; mr < MR; ++mr) {
-            float bv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = b1[cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr) {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = lrelu_f(acc[mr][nr][r] + bv[r], slope);  // max(v, slope v): the compare-and-select form's value for every finite v (bf16_common.h)
+                for (int r = 0; r < 16; ++r) v[r] = lrelu_f(acc[mr][nr][r], slope);  // (b1 is in the sum already) max(v, slope v): the compare-and-select form's value for every finite v (bf16_common.h)
                 if (!interior) {  // (workgroup-uniform branch: all but an utterance's first and last windows skip the 16 v_cndmask per block — 19 cycles each alone, profiles/r03_a_coissue_findings.md)
                     const int t = tw + col0 + nr * 32;
                     const bool ok = t >= 0 && t < L;
@@ -334,26 +345,18 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
                 write_tile(aHi, aLo, mr, nr, v);
             }
         }
-        zero_acc();
         __syncthreads();  // xt written
         RX_TL(5 + 6 * pr);
         // ---- c2 over the tile (rate 1) ----
-        conv_phase(std::integral_constant<int, KSTEPS>{}, p.w[2 * pr + 1], pr < 2 ? p.w[2 * pr + 2] : nullptr, 1, aHi, aLo);
+        conv_phase(std::integral_constant<int, KSTEPS>{}, b2, p.w[2 * pr + 1], pr < 2 ? p.w[2 * pr + 2] : nullptr, 1, aHi, aLo);
         RX_TL(6 + 6 * pr);
         // ---- x = (c2 + b2) + x  (model.py:50), in fp32 as the pair path's epilogue 2 ----
 #pragma unroll
-        for (int mr = 0; mr < MR; ++mr) {
-            float bv[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bv[r] = b2[cb0 + mr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+        for (int mr = 0; mr < MR; ++mr)
 #pragma unroll
             for (int nr = 0; nr < NR; ++nr)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[mr][nr][r] + bv[r];
-                    xr[mr][nr][r] = v + xr[mr][nr][r];
-                }
-        }
+                for (int r = 0; r < 16; ++r) xr[mr][nr][r] = acc[mr][nr][r] + xr[mr][nr][r];  // (b2 is in the sum already)
         if (pr < 2) {
             __syncthreads();  // every wave is done reading xt
             RX_TL(7 + 6 * pr);
