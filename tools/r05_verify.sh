@@ -1,7 +1,7 @@
 #!/bin/bash
 # full GPU verification of the current build (round 5): tests, smoke, counters of this very build (bf16, fp32, bf16x3 engines), the bench line,
 # and the kernel statistics of the 256-sentence pipeline in its throughput and its parity-grade configuration
-TAG=${1:-r05_f}
+TAG=${1:-r05_g}
 O=gpurun_out/r05_verify; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -1
