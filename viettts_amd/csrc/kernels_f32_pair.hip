@@ -198,11 +198,7 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 const int tc = t < 0 ? 0 : (t >= LP ? LP - 4 : t);
                 v[i] = mask_tail4(*reinterpret_cast<const float4*>(xc + (long)row * a.x_sc + tc), t, L);
                 if (!ok) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[i] = idx < total ? idc : -1;  // in 16-byte units: row * w4 + c4 == idc (rsx = 4 * w4).  Indexing the tile as float4 lets hipcc see the
-                                                  // alignment: the float offset row * rsx + 4 * c4 (rsx a runtime value) came out as two ds_write2_b32 per store,
-                                                  // lanes 16 bytes apart writing 8 bytes each — 2-way bank conflicts, the 5.4-6.0e7 conflict cycles per launch
-                                                  // every class of this kernel showed (profiles/r04_i_f32_pmc.md; conv1d_f32_mfma_k, whose row stride is a
-                                                  // compile-time multiple of 4, gets ds_write_b128 and shows none)
+                dst[i] = idx < total ? row * rsx + 4 * c4 : -1;
             }
 #pragma unroll
             for (int i = 0; i < ITER; ++i) {
@@ -212,7 +208,7 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 q.y = lrelu(q.y, a.slope_in);
                 q.z = lrelu(q.z, a.slope_in);
                 q.w = lrelu(q.w, a.slope_in);
-                reinterpret_cast<float4*>(xs)[dst[i]] = q;
+                *reinterpret_cast<float4*>(&xs[dst[i]]) = q;
             }
         }
         __syncthreads();
@@ -234,10 +230,7 @@ __global__ __launch_bounds__(256, T::WPS) void resblock_pair_f32_k(PairArgsF32 p
                 const int tt = t0 - H2 + n;
                 float v = lrelu(acc[mr][nr][r] + bv, a.slope_in);  // LRELU_SLOPE for both activations of a pair (model.py:46,48)
                 if (tt < 0 || tt >= L) v = 0.0f;                   // c2's own zero padding applies to xt
-                // one ds_write_b32 per value (a half-wave = 32 consecutive columns of one channel: conflict-free).  hipcc merged the stores of two column
-                // blocks into ds_write2_b32 (offset1:32), whose two dwords of a 16-lane group fall on the same 16 banks: the other half of this
-                // kernel's LDS bank-conflict cycles
-                *(__attribute__((address_space(3))) volatile float*)(&xs[co * RST + n]) = v;  // (an LDS-qualified volatile: a generic one becomes flat_store_dword)
+                xs[co * RST + n] = v;
             }
         }
     for (int u = tid; u < C * 2 * H2; u += 256) {  // columns N1 .. N1 + 2*H2 - 1 are only read by the discarded output columns: keep them finite
