@@ -18,7 +18,7 @@ def test_two_ranks_share_one_gpu_and_shard_both_legs():
     env = dict(os.environ, VTTS_DIST_BACKEND="gloo", VTTS_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--frames", "128",
-           "--no-cpu-baseline", "--no-f32"]
+           "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
@@ -40,6 +40,11 @@ def test_two_ranks_share_one_gpu_and_shard_both_legs():
         assert two[k] == one[k], (k, two[k], one[k])
     lf = d["longform_10min"]
     assert lf["chunks"] == -(-37500 // 512) and lf["first_chunk_ms"] > 0 and lf["total_ms"] >= lf["first_chunk_ms"]
+    # the parity-grade peers of both legs shard the same way: every fixture sentence / window sample is checked by exactly one rank
+    pg = two["parity_grade"]
+    assert "error" not in pg and pg["oracle_chain_sentences_checked"] == 3 and pg["integer_frame_counts_equal"] is True and pg["max_abs_vs_oracle_chain"] < 1e-4
+    lpg = lf["parity_grade"]
+    assert "error" not in lpg and lpg["samples_compared"] == 3 * 16 * 256 and lpg["max_abs_vs_fp64_oracle_windows"] < 1e-4
 
 
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs: the first box that has them exercises RCCL without anyone remembering to")
