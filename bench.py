@@ -616,6 +616,11 @@ def main():
                 # calibration, not the contract's peak: a pure MFMA stream (operands in registers, no LDS / memory traffic) sustains 1750 TF/s on pseudo-random
                 # bf16 operands and 2460 on constant ones on this chip's power budget (profiles/r03_e_mfma_peak.txt, tools/kbench/coissue 400 3)
                 "peak_sustained_mfma_only_random_operands": 1750.0 if args.dtype == "bf16" else None,
+                # recorded, not measured in this run (round 5, profiles/r05_i_kstep_asm_findings.md): the dominant kernel's OWN k-step loop cut loose from staging and
+                # epilogues (weights from L2, activations from LDS, two workgroups per CU) sustains 1703 TF/s over 0.7 s at 1.33-1.35 kW / 1.74-1.79 GHz, and the
+                # MfmaUtil counter formula below reads 0.87 for it — the ceilings `achieved` and `mfma_util_dominant_kernel` are to be read against
+                "recorded_sustained_own_kstep_loop_tflops": 1703.0 if args.dtype == "bf16" else None,
+                "recorded_mfma_util_of_own_kstep_loop": 0.87 if args.dtype == "bf16" else None,
                 "traffic_algorithmic": 2.0 * B * (T * 64) * 128 * 2 if prof["kernel"].startswith("resblock_pair_g_bf16_k<GTile<128, 11") else None,
                 # flat numeric keys (the driver's `parsed.roofline` keeps numbers): MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)
                 "mfma_util_dominant_kernel": util.get("dominant_kernel") if util else None,
