@@ -41,7 +41,7 @@ typedef enum vtts_dtype {
     VTTS_BF16 = 1, /* bf16 operands, fp32 accumulate: v_mfma_f32_32x32x16_bf16                  */
     VTTS_BF16X3 = 2 /* the fp32 engine (fp32 activations in HBM, same layouts, same entry points) with the ResBlock convolutions — 96.8 % of
                        the FLOPs — on the bf16 matrix pipe with SPLIT operands: every product is three bf16 x bf16 terms (x1 w0 + x0 w1 + x0 w0,
-                       v = v0 + v1 the two-bf16-term split of an fp32 value), fp32 accumulate.  fp32-grade: whole-generator max-abs 1.6e-5 (measured: profiles/r05_*_bench.json, bf16x3_path.parity) against
+                       v = v0 + v1 the two-bf16-term split of an fp32 value), fp32 accumulate.  fp32-grade: whole-generator max-abs 1.5e-5 (measured at 64 x 1024 frames: BENCH_r05.json, bf16x3_path.parity), 3.0x the fp32 engine's throughput against
                        the reference (5x inside BASELINE.json's 1e-4) at 3/16 of the fp32 MFMA time (kernels_x3.hip, profiles/r04_b_split_findings.md) */
 } vtts_dtype;
 

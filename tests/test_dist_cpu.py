@@ -2,6 +2,7 @@
 the design has (the start-up weight broadcast) plus the optional end-of-job gather."""
 import os
 import socket
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -223,3 +224,32 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert not seen and "WORLD_SIZE=1" in str(e.value)
+
+
+def test_launch_env_and_ipc_mode_and_missing_port(monkeypatch):
+    """The N > 1 launch contract: every launcher hands its ranks HSA_ENABLE_IPC_MODE_LEGACY=0 (RCCL's HIP-IPC hand-off of device
+    buffers needs the dmabuf mode on these hosts; a value the caller exported wins), the rendezvous port is ONE free port the parent picked — never
+    a fixed default — and a rank that was launched without one fails with a message instead of meeting nobody."""
+    from viettts_amd import dist as vdist
+
+    port = vdist.free_port()
+    assert 1024 < port < 65536
+    e0, e1 = (vdist.launch_env(8, r, port=port, env={"PATH": "/bin"}) for r in (0, 7))
+    assert e0["MASTER_PORT"] == e1["MASTER_PORT"] == str(port) and e0["MASTER_ADDR"] == "127.0.0.1"
+    assert (e0["RANK"], e1["RANK"], e1["LOCAL_RANK"], e1["WORLD_SIZE"]) == ("0", "7", "7", "8")
+    assert e0["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert vdist.launch_env(2, 0, port=port, env={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"  # the caller's choice stands
+    with pytest.raises(ValueError):
+        vdist.launch_env(2, 0)  # no port: every rank would pick its own
+    for k in ("MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError, match="MASTER_PORT"):
+        vdist.init_process_group("gloo")
+
+
+def test_bench_sets_the_ipc_mode_before_importing_torch():
+    """bench.py is what the driver launches under torch.distributed.run: the switch has to be in the environment before the HIP runtime starts."""
+    src = (Path(__file__).resolve().parents[1] / "bench.py").read_text()
+    assert 0 < src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < src.index("import torch")

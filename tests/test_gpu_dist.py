@@ -1,7 +1,10 @@
 """The N > 1 launch path on a ONE-GPU box: `bench.py --gpus 2` self-launches two ranks under torch.distributed.run (127.0.0.1), both on
 cuda:0 (VTTS_SHARE_GPU=1), collectives over gloo (VTTS_DIST_BACKEND=gloo) — the weight-blob broadcast, the barriers, the max-over-ranks
 timing and the two sharded legs (256-sentence pipeline, 10-minute utterance) all execute.  A development check of the multi-GPU code
-path (the reference has no counterpart: vietTTS/hifigan/mel2wave.py:20-41 is single-device), never a measurement."""
+path (the reference has no counterpart: vietTTS/hifigan/mel2wave.py:20-41 is single-device), never a measurement.
+
+The tests do NOT put HSA_ENABLE_IPC_MODE_LEGACY into the children's environment: bench.py itself sets it (before it imports torch, and for the
+ranks its self-launch starts), so what runs here is the environment the driver's own ``torch.distributed.run ... bench.py --gpus N`` gets."""
 import json
 import os
 import subprocess
@@ -15,8 +18,9 @@ REPO = Path(__file__).resolve().parents[1]
 
 
 def test_two_ranks_share_one_gpu_and_shard_both_legs():
-    env = dict(os.environ, VTTS_DIST_BACKEND="gloo", VTTS_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("WORLD_SIZE", None)
+    env = dict(os.environ, VTTS_DIST_BACKEND="gloo", VTTS_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        env.pop(k, None)
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "2", "--frames", "128",
            "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
@@ -47,14 +51,44 @@ def test_two_ranks_share_one_gpu_and_shard_both_legs():
     assert "error" not in lpg and lpg["samples_compared"] == 3 * 16 * 256 and lpg["max_abs_vs_fp64_oracle_windows"] < 1e-4
 
 
+def test_eight_ranks_share_one_gpu_at_the_world_size_the_driver_uses():
+    """The driver's scaling run is N = 1, 2, 4, 8: the 256 sentences / 74 long-form chunks over EIGHT ranks, the per-rank timing gather, the
+    checksum MIN / MAX all-reduce and the leg combiners have to have executed at that world size before an 8-GPU node sees them (VERDICT r05
+    item 4).  Tiny headline batch (1 x 64 frames per rank); the two sharded legs run whole.  gloo, every rank on cuda:0."""
+    env = dict(os.environ, VTTS_DIST_BACKEND="gloo", VTTS_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--batch", "1", "--frames", "64", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["samples_per_step"] == 8 * 1 * 256 * 64
+    wb = d["weights_broadcast"]
+    assert wb["backend"] == "gloo" and wb["ranks_in_group"] == 8 and wb["blob_checksum_equal"] is True
+    assert len(d["ms_per_step_per_rank"]) == 8 and max(d["ms_per_step_per_rank"]) == pytest.approx(d["ms_per_step"], rel=1e-6)
+    import bench
+
+    one = bench.pipeline_256(256)
+    p = d["pipeline_256"]
+    assert "error" not in p, p
+    for k in ("sentences", "tokens", "frames", "samples"):  # every sentence synthesised exactly once, by one of the eight ranks
+        assert p[k] == one[k], (k, p[k], one[k])
+    pg = p["parity_grade"]
+    assert "error" not in pg and pg["oracle_chain_sentences_checked"] == 3 and pg["integer_frame_counts_equal"] is True and pg["max_abs_vs_oracle_chain"] < 1e-4
+    lf = d["longform_10min"]
+    assert lf["chunks"] == -(-37500 // 512) and lf["total_ms"] >= lf["first_chunk_ms"] > 0  # 74 chunks over 8 ranks: each exactly once
+    lpg = lf["parity_grade"]
+    assert "error" not in lpg and lpg["samples_compared"] == 3 * 16 * 256 and lpg["max_abs_vs_fp64_oracle_windows"] < 1e-4
+
+
 @pytest.mark.skipif("__import__('torch').cuda.device_count() < 2", reason="needs two GPUs: the first box that has them exercises RCCL without anyone remembering to")
 def test_two_gpus_real_rccl_broadcast_and_sharded_legs():
     """north_star: "weights RCCL-broadcast once over xGMI and no per-step collectives".  On a box with at least two GPUs the same self-launch entry
     runs with the REAL backend (torch.distributed "nccl" = RCCL), one rank per GPU: the packed blob travels over RCCL (``setup_model_dp``), every
     rank checksums what it received, and both sharded legs (and their parity-grade peers) complete.  Skipped on the one-GPU boxes of this build
     environment — where it has therefore never run."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VTTS_DIST_BACKEND", "VTTS_SHARE_GPU"):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "VTTS_DIST_BACKEND", "VTTS_SHARE_GPU", "HSA_ENABLE_IPC_MODE_LEGACY"):
         env.pop(k, None)
     cmd = [sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "4", "--frames", "256", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=1200)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Digest the per-workgroup phase stamps of resblock_x3_k (kernels_x3_rb.hip, VTTS_RX_TL=<file>): mean ticks per phase over the workgroups that ran.
-    VTTS_RX_TL=/tmp/tl.bin VTTS_RX_TL_K=3 python tools/rx_timeline.py run      (runs one 64 x 1024 pass on the split engine, then digests)
+    python -m viettts_amd.csrc.build --define VTTS_TIMELINE=1 --libname libvtts_tl.so      (the stamps are compiled into development builds only)
+    VTTS_HIFIGAN_LIB=$PWD/viettts_amd/lib/libvtts_tl.so VTTS_RX_TL=/tmp/tl.bin VTTS_RX_TL_K=3 python tools/rx_timeline.py run      (runs one 64 x 1024 pass on the split engine, then digests)
     python tools/rx_timeline.py /tmp/tl.bin"""
 import os
 import sys

@@ -624,8 +624,24 @@ int run_resblock_x3(vtts_hifigan* h, const Layer* rb, const float* x, int B, int
         w[q] = h->blob + rb[q].off_x3;
         bias[q] = reinterpret_cast<const float*>(h->blob + rb[q].off_b);
     }
+    // option "profile": a class the whole-ResBlock kernel serves is bracketed like the pair launches it replaces (six convolutions per launch)
+    const bool prof = h->opt_profile && rb[0].cin == h->prof_C && rb[0].k == h->prof_K;
+    if (prof) {
+        if (h->prof_used == h->prof_events.size()) {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            h->prof_events.emplace_back(e0, e1);
+        }
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].first, s));
+    }
     hipError_t e = launch_resblock_x3(a, dils, w, bias, s);
     if (e != hipSuccess) return fail(VTTS_ERR_HIP, "split-operand ResBlock launch for %s failed: %s", rb[0].key.c_str(), hipGetErrorString(e));
+    if (prof) {
+        HIP_TRY(hipEventRecord(h->prof_events[h->prof_used].second, s));
+        h->prof_used++;
+        h->prof_flops += 6 * 2.0 * (double)B * L * rb[0].cin * rb[0].cin * rb[0].k;
+    }
     return VTTS_OK;
 }
 

@@ -27,10 +27,10 @@
 //     (12 / 36 / 60 for k = 3 / 7 / 11); only the W - 2 M centre rows are stored;
 //   * zero padding: every convolution of the reference pads ITS input with zeros outside [0, L): every tile write masks rows outside the
 //     utterance (ragged batches: L = the utterance's valid length).
-// Arithmetic: the SAME sequence of operations per output element as three launches of resblock_pair_x3_k (accumulators from zero, k-steps in
-// tap-major order, the three terms in the same order, bias added to the finished sum, fp32 residual add, the same masks) — the results are
-// BIT-IDENTICAL to the pair path (tests/test_gpu_x3.py::test_x3_whole_resblock_equals_the_pair_path), so every parity test of the split
-// engine covers this kernel.
+// Arithmetic: the SAME sequence of operations per output element as three launches of resblock_pair_x3_k (the bias is the C operand of every
+// block's first MFMA in BOTH kernels — the accumulators start from it, nothing is added afterwards —, k-steps in tap-major order, the three terms
+// in the same order, fp32 residual add, the same masks) — the results are BIT-IDENTICAL to the pair path
+// (tests/test_gpu_x3.py::test_x3_whole_resblock_equals_the_pair_path), so every parity test of the split engine covers this kernel.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,13 +49,16 @@ struct RbArgsX3 {
     int dils[3];           // the three pairs' rates
     const void* w[6];      // c1_0, c2_0, c1_1, c2_1, c1_2, c2_2: each [hi fragments][lo fragments] (kernels_x3.hip: pair_x3_pack)
     const float* bias[6];
-    int skew;              // start-up delay of the launch's SECOND batch of workgroups (units of 8128 shader clocks; launch_rx)
-    unsigned long long* dbg;  // kernel-development runs only (VTTS_RX_TL=<file>): per-workgroup s_memtime stamps at the phase boundaries; nullptr otherwise
+    unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE=1, VTTS_RX_TL=<file>): per-workgroup s_memtime stamps at the phase boundaries; nullptr otherwise
 };
+#if VTTS_TIMELINE
 #define RX_TL(i)                                                                                                   \
     do {                                                                                                           \
         if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 24 + (i)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#else
+#define RX_TL(i) do { } while (0)
+#endif
 
 template <int C_, int KS_, int W_, int WM_, int WN_, int WPS_, int KSX1_ = C_ / 16>
 struct RXTile {
@@ -110,18 +113,14 @@ __global__ __launch_bounds__(T::THREADS, T::WPS) void resblock_x3_k(RbArgsX3 p) 
     }
     const int t0 = tile * NT;  // first output time step
     if (t0 >= L) return;
-    // Two workgroups share a CU and every window takes the same time, so the two would run their MFMA loops together (each at half the pipe's
-    // rate) and then their epilogues together (the pipe idle): utilisation = MFMA time / (MFMA + VALU time).  The launch's second batch of
-    // workgroups — the ones that land beside the first 256 — starts half a window late; its successors inherit the offset.
-    if (p.skew > 0) {
-        const unsigned g = blockIdx.x + blockIdx.z * gridDim.x;
-        if (g >= 256u && g < 512u)
-            for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    // (A start-up skew of the launch's second batch of workgroups — so that the two workgroups of a CU alternate MFMA loops and epilogues — was
+    //  measured in round 5 and changed nothing: they de-phase by themselves, profiles/r05_c_x3_rb_findings.md.)
     const int tw = t0 - M;     // time of window row 0
     const bool interior = tw >= 0 && tw + W <= L;  // every row of the window lies inside the utterance: no clamps, no zero-padding masks (workgroup-uniform)
     RX_TL(0);
+#if VTTS_TIMELINE
     if (p.dbg && threadIdx.x == 0) p.dbg[((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 24 + 23] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     const float* __restrict__ xb = a.x + (long)b * C * LP;
     float* yb = a.y + (long)b * C * LP;
     float* const sbias = reinterpret_cast<float*>(lds + T::AREA_BYTES);  // [6][C]; written here, read from epilogue 1 of pair 0 on (two barriers later)
@@ -507,14 +506,20 @@ bool resblock_x3_preferred(int C, int K) { return C == 32 || (C == 64 && K <= 7)
 hipError_t launch_resblock_x3(const ConvArgs& a, const int* dils, const void* const* w, const float* const* bias, hipStream_t s) {
     RbArgsX3 p;
     p.a = a;
-    p.skew = 0;
     p.dbg = nullptr;
-    if (const char* tl = getenv("VTTS_RX_TL")) {  // kernel-development: stamps of ONE class (VTTS_RX_TL_K, default 3; C = VTTS_RX_TL_C, default 32), last launch wins; dumped right away (synchronous)
+#if VTTS_TIMELINE  // kernel-development builds only (--define VTTS_TIMELINE=1; tools/rx_timeline.py): not in the shipped library
+    static const char* const tl = getenv("VTTS_RX_TL");  // read once
+    if (tl) {  // kernel-development: stamps of ONE class (VTTS_RX_TL_K, default 3; C = VTTS_RX_TL_C, default 32), last launch wins; dumped right away (synchronous)
         const int kk = getenv("VTTS_RX_TL_K") ? atoi(getenv("VTTS_RX_TL_K")) : 3, cc = getenv("VTTS_RX_TL_C") ? atoi(getenv("VTTS_RX_TL_C")) : 32;
         if (a.K == kk && a.Cin == cc && a.Cin <= 64) {
             static unsigned long long* buf = nullptr;
+            static size_t buf_bytes = 0;
             const size_t nwg = (size_t)((a.L + 31) / 32 + 8) * a.B, bytes = nwg * 24 * 8;
-            if (!buf && hipMalloc(&buf, bytes) != hipSuccess) buf = nullptr;
+            if (bytes > buf_bytes) {  // a later launch of the class may be larger than the first
+                if (buf) (void)hipFree(buf);
+                buf_bytes = hipMalloc(&buf, bytes) == hipSuccess ? bytes : 0;
+                if (!buf_bytes) buf = nullptr;
+            }
             if (buf) {
                 (void)hipMemsetAsync(buf, 0, bytes, s);
                 p.dbg = buf;
@@ -537,14 +542,7 @@ hipError_t launch_resblock_x3(const ConvArgs& a, const int* dils, const void* co
             }
         }
     }
-    {  // kernel-development switch: VTTS_RX_SKEW="a,b,c" = the delay for k = 3, 7, 11 (units of 8128 clocks)
-        static int sk[3] = {-1, -1, -1};
-        if (sk[0] < 0) {
-            sk[0] = sk[1] = sk[2] = 0;
-            if (const char* e = getenv("VTTS_RX_SKEW")) sscanf(e, "%d,%d,%d", &sk[0], &sk[1], &sk[2]);
-        }
-        p.skew = a.K == 3 ? sk[0] : (a.K == 7 ? sk[1] : sk[2]);
-    }
+#endif
     for (int i = 0; i < 3; ++i) p.dils[i] = dils[i];
     for (int q = 0; q < 6; ++q) {
         p.w[q] = w[q];

@@ -1013,343 +1013,12 @@ __global__ __launch_bounds__(64 * KW) void nat_dec_lstm_k(NatLstmOps ops0, NatLs
     }
 }
 
-// ---- the decoder as ONE resident kernel per run of frames (round 4) -------------------------------------------------------------------------
-// The per-frame launches above lose most of their time around the matrix work: every launch finds its L2 cold (the kernel boundary invalidates
-// it: 17.5 MB of misses per LSTM step, the whole weight matrix again — profiles/r04_e_nat_decoder_findings.md), so a step streams 6-10 MB of
-// weights from the Infinity Cache that have not changed since the last frame, with its fp32 MFMAs busy 23 % of the step.  This kernel keeps the
-// workgroups of the per-frame grid ((8-unit slice, 64-sentence tile): 64 x tiles <= one per CU) RESIDENT for a run of frames:
-//   * the slice's weights never leave the CU: LSTM1's 96 KB in LDS, LSTM2's 160 KB in registers (80 per lane; `asm volatile` keeps the
-//     compiler from re-loading them), the cell states of the workgroup's (unit, sentence) pairs in two registers per lane;
-//   * a frame is three phases — LSTM1, LSTM2, projection + next frame's prenet (on the 16 workgroups of a tile that own a sentence group) —
-//     separated by a barrier among the 64 workgroups that share a SENTENCE TILE (tiles never exchange data, and a tile whose sentences are all
-//     done leaves the kernel);
-//   * the state (p, h1, h2) crosses workgroups through HBM as before, written with agent-scope (sc1, write-through) stores; after the barrier
-//     one wave per workgroup invalidates the caches (acquire fence) and the state is read with plain 16-byte loads.  Cache-wide RELEASE
-//     fences are what make a compiler-level grid sync cost 30+ us on this chip; this barrier measures 2-4 us
-//     (tools/kbench/grid_barrier.hip: modes 1 and 4).
-// Every sum is the per-frame kernels' sum in the order they had when this was measured (commit 99b5d03: a tree over the K shares; they have since
-// moved to a one-barrier sum): the mel was bit-identical to theirs (tools/experiments/r04/persist_check.py at that commit).  The
-// spin is bounded: a barrier that is not met within ~seconds (a grid that is not resident: another resident kernel on the device) traps
-// instead of hanging.
-// **MEASURED, AND NOT SHIPPED (round 4): 26.7 ms for the acoustic model of 256 sentences against 22.4 with the per-frame launches.**  Per frame
-// (shader clocks / 2.2 GHz): LSTM1 10.8 us, barrier 4.0, LSTM2 14.0, barrier 3.0, projection + prenet 31 (8 waves instead of 16 for
-// latency-bound work), barrier 5: 68 us against 48.5.  Why the LSTM phases run at twice their MFMA time although the weights never leave the
-// CU: the L2s of the 8 XCDs are not coherent with one another, so a workgroup must invalidate its XCD's L2 after every barrier — 32 workgroups
-// per XCD doing so at slightly different times leave nothing in it, and each of the 64 workgroups of a tile pulls the tile's whole state from
-// the Infinity Cache itself (131 MB per frame instead of ~10: the per-frame launches invalidate once, and seven of a slice's eight XCD
-// neighbours then hit in L2).  The kernel is compiled only with -DVTTS_NAT_PERSIST (tools/experiments/r04/persist_check.py builds that
-// variant and checks the bit-identity); profiles/r04_e_nat_decoder_findings.md has the numbers.
+// (Round 4 built the decoder as ONE resident kernel per run of frames — bit-identical, 26.7 ms against 22.4 with the per-frame launches; the L2s of the 8 XCDs
+//  are not coherent, so every barrier costs the workgroups their cached state — and did not ship it: profiles/r04_e_nat_decoder_findings.md.  The kernel lives in
+//  tools/kbench/experiments/nat_persist_*.inc and is compiled only into experiment builds: --define VTTS_NAT_PERSIST=1.)
 #ifdef VTTS_NAT_PERSIST
-struct NatPersistArgs {
-    const float4* w1;  // LSTM1 [slice][(PN + H) / 8][lane] float4 (add_lstm_mfma order)
-    const float4* w2;  // LSTM2 [slice][(PN + 2H) / 8][lane]
-    const float* G1;   // hoisted gate pre-activations [sentence][frame][4H] (accumulator order)
-    const float* G2;
-    float* Z0;         // state, parity 0 and 1: rows [p | h1 | h2], nat_zidx layout
-    float* Z1;
-    float* c1;         // cell states [H][Bp]: read at the first frame of the run, written after its last
-    float* c2;
-    const int* nframes;
-    const float4* f1;  // prenet / projection matrices, "#k4" order
-    const float4* f2;
-    const float4* wp;
-    const float* bp;
-    const unsigned char* keep;
-    float* mel;        // decoder output [B][Fmax][MEL]
-    unsigned* ctl;     // ctl[64 * tile] = the tile's barrier counter (zero at launch); ctl[1000] = failure flag
-    unsigned long long* clocks;  // development builds (VTTS_NAT_PERSIST_CLOCKS): per-workgroup phase clocks, or nullptr
-    int f_begin, f_end, B, Bp, Fmax, MEL;
-};
-typedef float nat_v4f __attribute__((ext_vector_type(4)));
-
-template <int PN, int H, int NT>
-__global__ __launch_bounds__(512) void nat_dec_persist_k(NatPersistArgs a) {
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    constexpr int KW = 8, PD = NAT_DEC_PD, NIT1 = (PN + H) / 8, NIT2 = (PN + 2 * H) / 8, NW1 = NIT1 / KW, NW2 = NIT2 / KW, G4 = 4 * H;
-    constexpr int MEMBERS = H / 8;  // workgroups per sentence tile
-    static_assert(NIT1 % KW == 0 && NIT2 % KW == 0 && NT * 4 <= KW, "one cell-update block per wave at most");
-    extern __shared__ float4 lds4[];
-    nat_v4f* w1s = reinterpret_cast<nat_v4f*>(lds4);  // [NIT1][64]
-    float* red = reinterpret_cast<float*>(lds4 + NIT1 * 64);  // [KW / 2][NT][16][64] in the LSTM phases; the projection's buffers in phase C
-    const int lane = threadIdx.x & 63, kw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, lh = lane >> 5;
-    const int slice = blockIdx.x, tile = blockIdx.y, b0 = tile * 32 * NT, B = a.B, Bp = a.Bp;
-    // the state through buffer loads: one 32-bit per-lane offset for the whole run, the row block as a scalar offset (64-bit per-lane addresses
-    // for every unrolled load of both parities were hoisted out of the frame loop and spilled)
-    const int zbytes = (PN + 2 * H) * Bp * 4;
-    const auto rs_z0 = __builtin_amdgcn_make_buffer_rsrc(a.Z0, 0, zbytes, 0x00020000);
-    const auto rs_z1 = __builtin_amdgcn_make_buffer_rsrc(a.Z1, 0, zbytes, 0x00020000);
-    const int x_voff = (lh * Bp + b0 + l31) * 16;
-    int nfr[NT], tmax = 0;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int b = b0 + 32 * nt + l31;
-        nfr[nt] = b < B ? a.nframes[b] : 0;
-        tmax = nfr[nt] > tmax ? nfr[nt] : tmax;
-    }
-    for (int o = 16; o > 0; o >>= 1) {
-        const int v = __shfl_xor(tmax, o, 64);
-        tmax = v > tmax ? v : tmax;
-    }
-    const int fend = a.f_end < tmax ? a.f_end : tmax;  // the same for all workgroups of the tile: they meet the same barriers or none
-    if (a.f_begin >= fend) return;
-    // the slice's weights, for the whole run
-    for (int i = threadIdx.x; i < NIT1 * 64; i += 512) w1s[i] = reinterpret_cast<const nat_v4f*>(a.w1)[(size_t)slice * NIT1 * 64 + i];
-    nat_v4f w2r[NW2];
-#pragma unroll
-    for (int i = 0; i < NW2; ++i) {
-        w2r[i] = reinterpret_cast<const nat_v4f*>(a.w2)[((size_t)slice * NIT2 + kw * NW2 + i) * 64 + lane];
-        asm volatile("" : "+v"(w2r[i]));  // opaque from here on: the value stays in its registers, no re-load from memory inside the frame loop
-    }
-    // this wave's cell-update block: (sentence half-tile, unit pair) = (kw / 4, kw % 4)
-    const bool has_blk = kw < NT * 4;
-    const int nt_c = kw >> 2, rq_c = kw & 3, u_c = 8 * slice + 2 * rq_c + lh, b_c = b0 + 32 * nt_c + l31;
-    const int nf_c = nt_c == 0 ? nfr[0] : nfr[NT - 1];  // this block's sentences' frame counts (a register-array index must be a constant)
-    float c1r = has_blk ? a.c1[(size_t)u_c * Bp + b_c] : 0.0f, c2r = has_blk ? a.c2[(size_t)u_c * Bp + b_c] : 0.0f;
-    __syncthreads();
-
-    unsigned* ctr = a.ctl + 64 * tile;
-    unsigned* failp = a.ctl + 1000;
-    unsigned passed = 0;
-    auto tile_barrier = [&]() {
-        ++passed;
-        __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have reached the point of coherence
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            if (threadIdx.x == 0) {
-                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                unsigned spins = 0;
-                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < passed * MEMBERS) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 23)) {
-                        __hip_atomic_store(failp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_trap();
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    };
-
-    auto lstm_phase = [&](auto tag, bool odd, const float* __restrict__ gin, float& creg, float* __restrict__ hout, int f) {
-        constexpr int L = decltype(tag)::value;
-        constexpr int KA = L == 0 ? PN : PN + H, NW = L == 0 ? NW1 : NW2;
-        const int it_lo = kw * NW;
-        f32x16 acc[NT][2];
-        if (kw == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int b = b0 + 32 * nt + l31;
-                const float4* __restrict__ gp = reinterpret_cast<const float4*>(gin + ((size_t)(b < B ? b : B - 1) * a.Fmax + f) * G4 + (size_t)(2 * slice + lh) * 16);
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float4 g4 = gp[rq];
-                    acc[nt][0][4 * rq + 0] = g4.x;
-                    acc[nt][0][4 * rq + 1] = g4.y;
-                    acc[nt][0][4 * rq + 2] = g4.z;
-                    acc[nt][0][4 * rq + 3] = g4.w;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[nt][1][4 * rq + i] = 0.0f;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[nt][0][r] = acc[nt][1][r] = 0.0f;
-        }
-        nat_v4f xv[PD][NT];
-        // state rows [k0, k0 + 8): the first KA rows (p, and h1 in layer 2) are this frame's, the rest the previous frame's (the other parity)
-        auto load_x = [&](int i, int slot) {
-            const int k0 = (it_lo + i) * 8;
-            const bool from1 = (k0 < KA) == odd;  // this frame's state is parity f & 1
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                xv[slot][nt] = __builtin_bit_cast(nat_v4f, __builtin_amdgcn_raw_buffer_load_b128(from1 ? rs_z1 : rs_z0, x_voff + nt * 512, k0 * Bp * 4, 0));
-        };
-#pragma unroll
-        for (int j = 0; j < PD; ++j)
-            if (j < NW) load_x(j, j);
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            const int j = i % PD;
-            nat_v4f wv;
-            if constexpr (L == 0) wv = w1s[(it_lo + i) * 64 + lane];
-            else wv = w2r[i];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv[j][nt].x, acc[nt][0], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv[j][nt].y, acc[nt][1], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv[j][nt].z, acc[nt][0], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv[j][nt].w, acc[nt][1], 0, 0, 0);
-            if (i + PD < NW) load_x(i + PD, j);
-            __builtin_amdgcn_sched_barrier(0);  // the unrolled iterations stay in order: hoisting all their loads to the top costs 70+ spilled registers
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[nt][0][r] += acc[nt][1][r];
-        // the per-frame kernel's tree over the K shares, then its shared-out cell update
-#pragma unroll
-        for (int half = KW / 2; half >= 1; half >>= 1) {
-            if (kw >= half && kw < 2 * half) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) red[(((kw - half) * NT + nt) * 16 + r) * 64 + lane] = acc[nt][0][r];
-            }
-            __syncthreads();
-            if (kw < half) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nt][0][r] += red[((kw * NT + nt) * 16 + r) * 64 + lane];
-            }
-            if (half > 1) __syncthreads();
-        }
-        if (kw == 0) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[(nt * 16 + r) * 64 + lane] = acc[nt][0][r];
-        }
-        __syncthreads();
-        if (has_blk && f < nf_c) {
-            const float gi = red[(nt_c * 16 + 4 * rq_c + 0) * 64 + lane], gg = red[(nt_c * 16 + 4 * rq_c + 1) * 64 + lane];
-            const float gf = red[(nt_c * 16 + 4 * rq_c + 2) * 64 + lane], go = red[(nt_c * 16 + 4 * rq_c + 3) * 64 + lane];
-            float c = creg;
-            c = sigmoidf_(gf + 1.0f) * c + sigmoidf_(gi) * tanhf(gg);
-            creg = c;
-            __hip_atomic_store(hout + nat_zidx(u_c, b_c, Bp), sigmoidf_(go) * tanhf(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-
-    // phase C: nat_dec_proj_prenet_k's arithmetic for the 4 sentences b0c .. b0c + 3 on 512 threads (a thread takes the items g and g + 512)
-    const int MEL = a.MEL, Fmax = a.Fmax;
-    float4* hs = reinterpret_cast<float4*>(red);  // [2H]
-    float4* part = hs + 2 * H;                    // [1024]
-    float4* prev = part + 1024;                   // [MEL]
-    float4* p1 = prev + MEL;                      // [PN]
-    const bool proj_wg = slice < 8 * NT;
-    const int b0c = b0 + 4 * slice;
-    int nfc[4] = {0, 0, 0, 0};
-    if (proj_wg) {
-#pragma unroll
-        for (int sI = 0; sI < 4; ++sI) nfc[sI] = b0c + sI < B ? a.nframes[b0c + sI] : 0;
-    }
-    auto proj_phase = [&](const float* __restrict__ zcur, float* __restrict__ znext, int f) {
-        const bool any = f < nfc[0] || f < nfc[1] || f < nfc[2] || f < nfc[3];
-        if (!any) return;
-        for (int k = threadIdx.x; k < 2 * H; k += 512) {
-            const float* __restrict__ zr = zcur + nat_zidx(PN + k, b0c, Bp);
-            hs[k] = make_float4(zr[0], zr[4], zr[8], zr[12]);
-        }
-        __syncthreads();
-        auto partial = [&](const float4* __restrict__ src, const float4* __restrict__ w4, int rows, int width, int col, int ch, int per) {
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;
-#pragma unroll 4
-            for (int k = ch * per; k < k1; k += 4) {
-                const float4 wv = w4[(size_t)(k >> 2) * width + col];
-                const float4 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
-                q.x = fmaf(x0.x, wv.x, q.x); q.y = fmaf(x0.y, wv.x, q.y); q.z = fmaf(x0.z, wv.x, q.z); q.w = fmaf(x0.w, wv.x, q.w);
-                q.x = fmaf(x1.x, wv.y, q.x); q.y = fmaf(x1.y, wv.y, q.y); q.z = fmaf(x1.z, wv.y, q.z); q.w = fmaf(x1.w, wv.y, q.w);
-                q.x = fmaf(x2.x, wv.z, q.x); q.y = fmaf(x2.y, wv.z, q.y); q.z = fmaf(x2.z, wv.z, q.z); q.w = fmaf(x2.w, wv.z, q.w);
-                q.x = fmaf(x3.x, wv.w, q.x); q.y = fmaf(x3.y, wv.w, q.y); q.z = fmaf(x3.z, wv.w, q.z); q.w = fmaf(x3.w, wv.w, q.w);
-            }
-            return q;
-        };
-        auto gather = [&](float4 q, int width, int col, int nch) {
-            for (int ch = 0; ch < nch; ++ch) {
-                const float4 v = part[ch * width + col];
-                q.x += v.x; q.y += v.y; q.z += v.z; q.w += v.w;
-            }
-            return q;
-        };
-        const int nchP = 1024 / MEL, perP = ((2 * H + nchP - 1) / nchP + 3) / 4 * 4;
-        for (int g = threadIdx.x; g < nchP * MEL; g += 512) part[g] = partial(hs, a.wp, 2 * H, MEL, g % MEL, g / MEL, perP);
-        __syncthreads();
-        if ((int)threadIdx.x < MEL) {
-            const int g = threadIdx.x;
-            const float bb = a.bp[g];
-            const float4 q = gather(make_float4(bb, bb, bb, bb), MEL, g, nchP);
-            prev[g] = q;
-            const float v[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int sI = 0; sI < 4; ++sI)
-                if (f < nfc[sI]) a.mel[((size_t)(b0c + sI) * Fmax + f) * MEL + g] = v[sI];
-        }
-        __syncthreads();
-        if (f + 1 >= Fmax) return;
-        auto masked = [&](float4 q, int which, int col) {
-            float v[4] = {fmaxf(q.x, 0.0f), fmaxf(q.y, 0.0f), fmaxf(q.z, 0.0f), fmaxf(q.w, 0.0f)};
-            if (a.keep) {
-#pragma unroll
-                for (int sI = 0; sI < 4; ++sI)
-                    if (b0c + sI < B) v[sI] = a.keep[(((size_t)(b0c + sI) * Fmax + f + 1) * 2 + which) * PN + col] ? v[sI] * 2.0f : 0.0f;
-            }
-            return make_float4(v[0], v[1], v[2], v[3]);
-        };
-        const int nchN = 1024 / PN;
-        for (int g = threadIdx.x; g < nchN * PN; g += 512) part[g] = partial(prev, a.f1, MEL, PN, g % PN, g / PN, ((MEL + nchN - 1) / nchN + 3) / 4 * 4);
-        __syncthreads();
-        if ((int)threadIdx.x < PN) p1[threadIdx.x] = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, threadIdx.x, nchN), 0, threadIdx.x);
-        __syncthreads();
-        for (int g = threadIdx.x; g < nchN * PN; g += 512) part[g] = partial(p1, a.f2, PN, PN, g % PN, g / PN, ((PN + nchN - 1) / nchN + 3) / 4 * 4);
-        __syncthreads();
-        if ((int)threadIdx.x < PN) {
-            const int g = threadIdx.x;
-            const float4 r = masked(gather(make_float4(0.f, 0.f, 0.f, 0.f), PN, g, nchN), 1, g);
-            float* __restrict__ zw = znext + nat_zidx(g, b0c, Bp);
-            __hip_atomic_store(zw + 0, r.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zw + 4, r.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zw + 8, r.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(zw + 12, r.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-
-#ifdef VTTS_NAT_PERSIST_CLOCKS  // development build: shader-clock cycles per phase, summed over the run by thread 0 of every workgroup -> ctl[256 + 8 * wg ...]
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t0 = __builtin_readcyclecounter();
-#define NAT_TICK(i)                                                  \
-    {                                                                \
-        const unsigned long long t1 = __builtin_readcyclecounter(); \
-        tacc[i] += t1 - t0;                                          \
-        t0 = t1;                                                     \
-    }
-#else
-#define NAT_TICK(i)
+#include "../../tools/kbench/experiments/nat_persist_kernel.inc"
 #endif
-    for (int f = a.f_begin; f < fend; ++f) {
-        float* zc = (f & 1) ? a.Z1 : a.Z0;
-        float* zp = (f & 1) ? a.Z0 : a.Z1;
-        lstm_phase(std::integral_constant<int, 0>{}, (f & 1) != 0, a.G1, c1r, zc + (size_t)PN * Bp, f);
-        NAT_TICK(0)
-        tile_barrier();
-        NAT_TICK(1)
-        lstm_phase(std::integral_constant<int, 1>{}, (f & 1) != 0, a.G2, c2r, zc + (size_t)(PN + H) * Bp, f);
-        NAT_TICK(2)
-        tile_barrier();
-        NAT_TICK(3)
-        if (proj_wg) proj_phase(zc, zp, f);
-        NAT_TICK(4)
-        tile_barrier();
-        NAT_TICK(5)
-    }
-#ifdef VTTS_NAT_PERSIST_CLOCKS
-    if (threadIdx.x == 0 && a.clocks) {
-        unsigned long long* out = a.clocks + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
-        for (int i = 0; i < 6; ++i) out[i] += tacc[i];
-        out[6] += (unsigned long long)(fend - a.f_begin);
-    }
-#endif
-    if (has_blk) {
-        a.c1[(size_t)u_c * Bp + b_c] = c1r;
-        a.c2[(size_t)u_c * Bp + b_c] = c2r;
-    }
-}
-#endif  // VTTS_NAT_PERSIST
 
 // ---- the decoder step with the option "bf16x3": the gate sums as three bf16 x bf16 terms per product on the bf16 matrix pipe ----------------
 // The state lives in HBM already split: Zx[parity][hi | lo][row / 8][Bp][8] bf16 (rows [p | h1 | h2]; h = hi + lo to 16 mantissa bits), so that a
@@ -1634,12 +1303,6 @@ __global__ void nat_keep_masks_haiku_k(unsigned k0, unsigned k1, int mode, unsig
 // mel_f = [h1 ; h2] @ wp + bp, then the prenet of frame f + 1 into the other parity's state.  One
 // 1024-thread workgroup per 4 sentences (weights read once per k for the four).  Every product is split over k into
 // 1024 / width partial sums that are added in chunk order: a frame step is latency-bound, short dependent chains matter.
-#ifndef VTTS_NAT_PKFMA
-#define VTTS_NAT_PKFMA 0
-#endif
-#ifndef VTTS_NAT_PK_NOP
-#define VTTS_NAT_PK_NOP 0
-#endif
 template <bool X3>  // X3: the state is the bf16x3 step's (two bf16 planes, nat_zxidx; `plane` elements apart); h = hi + lo exactly, p is split on its way out
 __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __restrict__ zcur, float* __restrict__ znext,
                                                               const int* __restrict__ nframes, const float4* __restrict__ f1, const float4* __restrict__ f2,
@@ -1689,41 +1352,8 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     auto partial = [&](const float4* __restrict__ src, const float4* __restrict__ w4, int rows, int width, int col, int ch, int per, int phase_bit) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         const int k1 = (ch + 1) * per < rows ? (ch + 1) * per : rows;  // per and rows are multiples of 4
-#if VTTS_NAT_PKFMA  // kernel-development builds ONLY (tools/experiments/r05/pkfma_bisect.sh): the packed-f32 form hipcc's SLP vectoriser made of this loop
-        // (v_pk_fma_f32 with src1 broadcast: sentences (0, 1) and (2, 3) as register pairs), written out, in the phases VTTS_NAT_PKFMA's bits name
-        // (1 = projection, 2 = prenet layer 1, 4 = prenet layer 2) — the round-4 miscompute beside the bf16 generator, bisected by phase
-        if (VTTS_NAT_PKFMA & phase_bit) {
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-            f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
-#pragma unroll 4
-            for (int k = ch * per; k < k1; k += 4) {
-                const float4 wv = w4[(size_t)(k >> 2) * width + col];
-                float4 x0 = src[k], x1 = src[k + 1], x2 = src[k + 2], x3 = src[k + 3];
-#if VTTS_NAT_PK_NOP  // bisect of the mechanism: wait states between the ARRIVAL of the loaded operands and the first packed instruction that reads them
-                // (bit 0: the LDS operands x, bit 1: the global-memory operand w; an asm that "modifies" a value forces its s_waitcnt in front of the asm)
-                float4 wq = wv;
-                if (VTTS_NAT_PK_NOP & 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(x0.x), "+v"(x0.y), "+v"(x0.z), "+v"(x0.w), "+v"(x1.x), "+v"(x1.y), "+v"(x1.z), "+v"(x1.w), "+v"(x2.x), "+v"(x2.y), "+v"(x2.z), "+v"(x2.w), "+v"(x3.x), "+v"(x3.y), "+v"(x3.z), "+v"(x3.w));
-#ifndef VTTS_NAT_PK_NOPSTR
-#define VTTS_NAT_PK_NOPSTR "s_nop 7\n\ts_nop 7"
-#endif
-                if (VTTS_NAT_PK_NOP & 2) asm volatile(VTTS_NAT_PK_NOPSTR : "+v"(wq.x), "+v"(wq.y), "+v"(wq.z), "+v"(wq.w));
-                if (VTTS_NAT_PK_NOP & 4) {  // a VALU copy of the loaded registers and NO wait states: the packed instruction then reads VALU-written registers
-                    float4 wc;
-                    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7" : "=&v"(wc.x), "=&v"(wc.y), "=&v"(wc.z), "=&v"(wc.w) : "v"(wq.x), "v"(wq.y), "v"(wq.z), "v"(wq.w));
-                    wq = wc;
-                }
-#define wv wq
-#endif
-                a01 = __builtin_elementwise_fma(f32x2_t{x0.x, x0.y}, f32x2_t{wv.x, wv.x}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x0.z, x0.w}, f32x2_t{wv.x, wv.x}, a23);
-                a01 = __builtin_elementwise_fma(f32x2_t{x1.x, x1.y}, f32x2_t{wv.y, wv.y}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x1.z, x1.w}, f32x2_t{wv.y, wv.y}, a23);
-                a01 = __builtin_elementwise_fma(f32x2_t{x2.x, x2.y}, f32x2_t{wv.z, wv.z}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x2.z, x2.w}, f32x2_t{wv.z, wv.z}, a23);
-                a01 = __builtin_elementwise_fma(f32x2_t{x3.x, x3.y}, f32x2_t{wv.w, wv.w}, a01); a23 = __builtin_elementwise_fma(f32x2_t{x3.z, x3.w}, f32x2_t{wv.w, wv.w}, a23);
-#if VTTS_NAT_PK_NOP
-#undef wv
-#endif
-            }
-            return make_float4(a01.x, a01.y, a23.x, a23.y);
-        }
+#ifdef VTTS_NAT_PKFMA  // bisect builds only (tools/experiments/r05/pkfma_build.sh): the packed-f32 variants of this loop, wrong by construction beside a bf16 MFMA stream
+#include "../../tools/kbench/experiments/nat_pkfma_partial.inc"
 #endif
 #pragma unroll 4
         for (int k = ch * per; k < k1; k += 4) {
@@ -2184,27 +1814,8 @@ VTTS_API int vtts_nat_acoustic_keep_masks_haiku(const vtts_nat_acoustic* h, uint
     return vtts_nat_acoustic_keep_masks_haiku_mode(h, rng_key0, rng_key1, 0, B, Fmax, keep_dev, stream);
 }
 #ifdef VTTS_NAT_PERSIST
-// experiment builds with -DVTTS_NAT_PERSIST_CLOCKS: a device buffer of per-workgroup phase clocks, dumped by vtts_nat_debug_persist_clocks()
-static unsigned long long* g_persist_clocks = nullptr;
-static unsigned long long* nat_persist_clocks() {
-#ifdef VTTS_NAT_PERSIST_CLOCKS
-    if (!g_persist_clocks) {
-        if (hipMalloc(&g_persist_clocks, 256 * 8 * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-        (void)hipMemset(g_persist_clocks, 0, 256 * 8 * sizeof(unsigned long long));
-    }
+#include "../../tools/kbench/experiments/nat_persist_host.inc"
 #endif
-    return g_persist_clocks;
-}
-#ifdef VTTS_NAT_PERSIST_CLOCKS
-VTTS_API int vtts_nat_debug_persist_clocks(unsigned long long* host_out) {  // [256][8]: six phase sums, frames, unused; zeroes the device buffer
-    if (!g_persist_clocks || !host_out) return VTTS_ERR_STATE;
-    if (hipDeviceSynchronize() != hipSuccess) return VTTS_ERR_HIP;
-    if (hipMemcpy(host_out, g_persist_clocks, 256 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return VTTS_ERR_HIP;
-    (void)hipMemset(g_persist_clocks, 0, 256 * 8 * sizeof(unsigned long long));
-    return VTTS_OK;
-}
-#endif
-#endif  // VTTS_NAT_PERSIST
 // forward() and forward_groups(): ngroups = 0 is the plain call (the postnet on the caller's stream after the last frame)
 // enc_pre: the token encoder's output [B][Lmax][2D] computed ahead by vtts_nat_acoustic_encode() (tokens_dev is not read then), or nullptr
 static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, const int32_t* lengths_dev, const float* durations_dev,
@@ -2364,41 +1975,7 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
         };
         bool persist = false;
 #ifdef VTTS_NAT_PERSIST
-        // The resident decoder kernel (nat_dec_persist_k; experiment builds only, see its comment) for the shipped architecture when the grid
-        // fits the chip one workgroup per CU; the environment variable VTTS_NAT_PERSIST=0 keeps the per-frame launches
-        int cus = 0, dev = 0;
-        HIP_TRYN(hipGetDevice(&dev));
-        HIP_TRYN(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        const bool persist_env = !(getenv("VTTS_NAT_PERSIST") && atoi(getenv("VTTS_NAT_PERSIST")) == 0);  // read per call: a test flips it
-        const int ptiles = wide ? Bp / 64 : 1;
-        persist = persist_env && PN == 256 && H == 512 && MEL <= 1024 && PN <= 1024 && (H / 8) * ptiles <= cus;
-        if (persist) {
-            const size_t red_bytes = (size_t)4 * (wide ? 2 : 1) * 16 * 64 * sizeof(float);
-            const size_t lds = (size_t)((PN + H) / 8) * 64 * sizeof(float4) + (plds > red_bytes ? plds : red_bytes);
-            const void* kfn = wide ? reinterpret_cast<const void*>(&nat_dec_persist_k<256, 512, 2>) : reinterpret_cast<const void*>(&nat_dec_persist_k<256, 512, 1>);
-            HIP_TRYN(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            // runs of frames between the points where the host has something to do: frame 64 (the gates of frames >= 64 come from the side stream)
-            // and the groups' last frames
-            std::vector<int> cuts;
-            if (Fmax > 64 && mtiles > mfirst) cuts.push_back(64);
-            for (int g = 0; g < ngroups; ++g) cuts.push_back(group_frames[g]);
-            cuts.push_back(Fmax);
-            std::sort(cuts.begin(), cuts.end());
-            cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
-            int fb = 0;
-            for (int fe : cuts) {
-                if (fe > fb) {
-                    if (fb == 64 && mtiles > mfirst) HIP_TRYN(hipStreamWaitEvent(s, h->ev_gates, 0));
-                    HIP_TRYN(hipMemsetAsync(ctl, 0, 4096, s));
-                    const NatPersistArgs pa{w1, w2, G1, G2, Z[0], Z[1], c1, c2, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, ctl, nat_persist_clocks(), fb, fe, B, Bp, Fmax, MEL};
-                    if (wide) hipLaunchKernelGGL((nat_dec_persist_k<256, 512, 2>), dim3(H / 8, ptiles), dim3(512), lds, s, pa);
-                    else hipLaunchKernelGGL((nat_dec_persist_k<256, 512, 1>), dim3(H / 8, ptiles), dim3(512), lds, s, pa);
-                    fb = fe;
-                }
-                rc = group_handover(fe);
-                if (rc) return rc;
-            }
-        }
+#include "../../tools/kbench/experiments/nat_persist_launch.inc"
 #endif
         // option "bf16x3": the split-state step (nat_dec_lstm_x3_k) where its 16-row steps divide the row blocks; the state's two parities hold
         // two bf16 planes each (the same bytes as the fp32 rows)

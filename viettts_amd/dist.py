@@ -32,18 +32,59 @@ def rank_info() -> RankInfo:
     return RankInfo(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")))
 
 
+def ipc_env(env=None):
+    """``HSA_ENABLE_IPC_MODE_LEGACY=0`` in ``env`` (default: this process's environment) unless the caller already chose a value.
+    RCCL's intra-node transport hands device buffers between the ranks' processes through HIP IPC handles; on hosts whose kernel driver
+    only offers dmabuf IPC (the MI355X boxes this build runs on) the legacy mode fails with ``hipIpcGetMemHandle: invalid argument``
+    at the first collective.  The HSA runtime reads the variable when it initialises, so it has to be in the environment BEFORE the
+    process's first HIP call: the launchers (``bench.py`` before it imports torch, and its self-launch) set it for their children; calling this
+    from :func:`init_process_group` covers a host that initialises HIP lazily after it."""
+    e = os.environ if env is None else env
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return e
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def init_process_group(backend: Optional[str] = None) -> RankInfo:
-    """One process per GPU.  backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests."""
+    """One process per GPU.  backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests.
+    The rendezvous address comes from the launcher (``torch.distributed.run`` exports MASTER_ADDR / MASTER_PORT); without one the address
+    defaults to 127.0.0.1, and a missing MASTER_PORT is an error for world > 1 — ranks that each picked "a free port" would never meet, and a
+    fixed default collides with whatever else runs on the node (use :func:`launch_env` to build the children's environment)."""
     info = rank_info()
     if info.world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        ipc_env()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            raise RuntimeError("viettts_amd.dist.init_process_group: WORLD_SIZE > 1 but MASTER_PORT is not set — launch the ranks with "
+                               "torch.distributed.run (bench.py --gpus N does) or export the port viettts_amd.dist.launch_env() picked")
         if backend == "nccl":
             torch.cuda.set_device(info.local_rank)
         dist.init_process_group(backend=backend, rank=info.rank, world_size=info.world)
     return info
+
+
+def launch_env(world: int, rank: int, local_rank: Optional[int] = None, port: Optional[int] = None, env=None) -> dict:
+    """Environment of one rank for a launcher that does not go through ``torch.distributed.run``: RANK / WORLD_SIZE / LOCAL_RANK, the
+    rendezvous on 127.0.0.1 at ``port`` (the PARENT takes a free one once — :func:`free_port` — and hands the same number to every rank)
+    and the IPC mode RCCL needs (:func:`ipc_env`)."""
+    e = dict(os.environ if env is None else env)
+    if port is None:
+        raise ValueError("launch_env: the parent picks ONE port (viettts_amd.dist.free_port()) and passes it to every rank")
+    e.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if local_rank is None else local_rank), MASTER_ADDR="127.0.0.1",
+             MASTER_PORT=str(port))
+    return ipc_env(e)
+
+
+free_port = _free_port
 
 
 # ---------------------------------------------------------------------------------------------------

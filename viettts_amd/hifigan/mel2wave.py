@@ -8,11 +8,11 @@ none of them observable in the output: the config and the 55.7 MB pickle are rea
 MI355X through the HIP library instead of un-jitted XLA-CPU ops.
 
 Engine: the drop-in runs the **fp32** engine by default — the one that meets the reference's numerics (<= 1e-4 max-abs
-against the Haiku generator, BASELINE.json) at ~4e7 samples/s.  ``VTTS_MEL2WAVE_DTYPE=bf16`` in the environment (or
+against the Haiku generator, BASELINE.json; measured 1.5e-6) at ~5.0e7 samples/s.  ``VTTS_MEL2WAVE_DTYPE=bf16`` in the environment (or
 ``FLAGS.dtype = "bf16"``) selects the bf16 throughput engine (~4e8 samples/s batched, max-abs ~1e-2 / 45 dB SNR against
 the same reference: bench.py ``parity_bf16``); ``bf16x3`` the split-operand engine (the fp32 engine's layouts with the ResBlock
-convolutions on the bf16 matrix pipe, three bf16 products per term: 1.6e-5 against the same reference at 64 x 1024 frames (profiles/r05_*_bench.json: bf16x3_path.parity) — inside the 1e-4 bar — at
-~2.4x the fp32 engine's batched throughput: bench.py ``bf16x3_path``).
+convolutions on the bf16 matrix pipe, three bf16 products per term: 1.5e-5 against the same reference at 64 x 1024 frames — inside the 1e-4 bar — at
+~3.0x the fp32 engine's batched throughput: bench.py ``bf16x3_path.parity`` / ``.speedup_vs_fp32_engine``, BENCH_r05.json).
 
 Errors follow the reference: a missing config / checkpoint raises ``FileNotFoundError``; a wrong
 mel shape raises ``ValueError``.

@@ -1,7 +1,7 @@
 """Constants of the NAT front end that the call surface needs (reference: vietTTS/nat/config.py:8-59).
 
-Only what ``text2tokens`` / the frame-count arithmetic / the duration model / the CLI read is mirrored here;
-training knobs and the acoustic model's dimensions belong to rows of SURVEY.md §8f that are not built yet.
+What ``text2tokens``, the frame-count arithmetic, the duration model, the acoustic model's inference path
+(``viettts_amd/nat/acoustic.py``) and the CLI read is mirrored here; training knobs are out of scope.
 """
 from pathlib import Path
 

@@ -88,7 +88,8 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
     wall seconds per stage.  The stages run one after the other on the caller's stream; a pass's waveforms leave for pinned host memory
     on a copy stream while the next pass computes.  Masks are seeded by the GLOBAL sentence index and every stage computes a row
     independently of its batch, so the samples depend neither on the shard nor on the batch (tests/test_gpu_nat.py: bit-identical to each
-    sentence alone).  ``generator`` may be any engine: bf16 (throughput; ~1e-2), bf16x3 or f32 (the reference's 1e-4)."""
+    sentence alone on the bf16 and bf16x3 engines; ~1e-7 on f32, whose transposed convolution picks its kernel — and with it a summation
+    order — by the pass's slot length).  ``generator`` may be any engine: bf16 (throughput; ~1e-2), bf16x3 or f32 (the reference's 1e-4)."""
     import time
 
     def mark(name, t_prev, sync=True):
@@ -162,7 +163,14 @@ def synthesize_sentences(token_lists: Sequence[Sequence[int]], duration_model, a
         todo = sorted((r for r in range(len(ok)) if gfr[ok[r]] > 0), key=lambda r: gfr[ok[r]])
         for rows in _generator_batches(todo, [gfr[ok[r]] for r in todo], gen_batch if ragged else 1, pf):
             fr = [gfr[ok[r]] for r in rows]
-            batch = mel_dev[torch.tensor(rows, device=dev), : max(fr)].contiguous()  # a device-side gather (plumbing)
+            # the pass's slot length: the longest sentence, rounded up to a multiple of 4 frames (the fp32 engine's MFMA transposed convolution takes
+            # lengths that are multiples of 4; an odd slot sent ups_0 of every utterance of the pass through the generic kernel).  Rows past a
+            # sentence's own frames are masked by frames[] inside the kernels, so the pad (zeros: mel_dev's tail, or zeros appended here) is never read as data.
+            Ts = -(-max(fr) // 4) * 4
+            batch = mel_dev[torch.tensor(rows, device=dev), : min(Ts, mel_dev.shape[1])]  # a device-side gather (plumbing)
+            if batch.shape[1] < Ts:
+                batch = torch.nn.functional.pad(batch, (0, 0, 0, Ts - batch.shape[1]))
+            batch = batch.contiguous()
             w = generator.forward_ragged(batch, fr) if ragged else generator(batch)
             # pinned, on a copy stream: the next pass computes while this one's samples leave
             done = torch.cuda.Event()

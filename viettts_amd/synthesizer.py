@@ -4,7 +4,8 @@ Same flags, defaults and prints; the text normalisation applies the reference's 
 reference's order (:21-31).  Unlike the reference this module has a ``main()`` (importing the
 reference runs the whole pipeline at import time).  One addition:
 ``--mel-file`` synthesises from a saved ``[T, 80]`` / ``[1, T, 80]`` float32 mel (.npy) so the
-mel->waveform path can be driven end to end while the NAT networks are unbuilt.
+mel->waveform path can be driven on its own (the text path runs the NAT duration and acoustic models of
+``viettts_amd/nat`` like the reference's).
 
     python -m viettts_amd.synthesizer --text "..." --output clip.wav --lexicon-file assets/infore/lexicon.txt
 """
