@@ -203,12 +203,13 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
 
     seen = {}
 
-    def fake_execv(exe, argv):
-        seen["exe"], seen["argv"] = exe, list(argv)
+    def fake_execve(exe, argv, env):
+        seen["exe"], seen["argv"], seen["env"] = exe, list(argv), dict(env)
         raise SystemExit(0)
 
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    monkeypatch.setattr(bench.os, "execv", fake_execv)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setattr(bench.os, "execve", fake_execve)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     with pytest.raises(SystemExit):
         bench.main()
@@ -217,6 +218,7 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
     assert "--nnodes=1" in a and "--nproc-per-node=4" in a
     assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
     assert a[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and a[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"  # the ranks' RCCL needs the dmabuf IPC mode
     # a launcher that started the wrong number of ranks is refused before any GPU work
     monkeypatch.setenv("WORLD_SIZE", "1")
     monkeypatch.setenv("RANK", "0")
