@@ -332,6 +332,7 @@ def main():
     ap.add_argument("--chains", type=int, default=-1, help="engine option 'chains' (0 / 1 / 2; -1 = engine default)")
     ap.add_argument("--fuse", type=int, default=-1, help="engine option 'fuse' (0..3; -1 = engine default)")
     ap.add_argument("--tail", type=int, default=-1, help="engine option 'tail' (bf16: conv_post inside the last pair launch; 0 / 1; -1 = engine default)")
+    ap.add_argument("--stage", type=int, default=-1, help="engine option 'stage' (bf16: the whole last stage in one launch; 0 / 1; -1 = engine default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rtf", action="store_true")
     args = ap.parse_args()
@@ -366,6 +367,8 @@ def main():
         gen.set_option("fuse", args.fuse)
     if args.tail >= 0:
         gen.set_option("tail", args.tail)
+    if args.stage >= 0:
+        gen.set_option("stage", args.stage)
     bstats = {}
     vdist.setup_generator_dp(gen, lambda: synthetic_params(V1, 4321, "scaled"), info, bstats)
 

@@ -204,6 +204,9 @@ int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const float* x_de
  *   "tail"      VTTS_BF16: 1 (default) = the generator's last pair launch (stage 4, C = 32, k = 11) also runs conv_post + tanh on the rows it
  *               produces — the stage output is never written and the streaming conv_post kernel is not launched; bit-identical samples;
  *               0 = the separate kernel.  (forward_tap always takes the separate kernel: a tap wants the stage output.)
+ *   "stage"     VTTS_BF16: 1 = the generator's whole LAST stage (ups_3's output -> three ResBlocks -> MRF mean -> LeakyReLU(0.01) -> conv_post -> tanh) is one
+ *               launch over LDS-resident windows (kernels_bf16_stage.hip); bit-identical samples.  0 (default): it measured 30 % slower than the launches it
+ *               replaces (profiles/r06_a_stage_kernel_findings.md).  forward_tap always takes the other path.
  *   "tiles"     MFMA time-tile width: 0 = by problem size, 1 = wide, 2 = narrow
  *   "zigzag"    1 (default) = consecutive launches walk the batch in alternating directions, so that a launch starts with the
  *               utterances its producer wrote last (still in the 256 MB Infinity Cache); same samples either way.  0 = always ascending.

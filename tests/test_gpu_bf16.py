@@ -288,6 +288,7 @@ def test_stage4_tail_fusion_is_bit_identical(tiles):
     gen = Generator(V1, device="cuda:0", dtype="bf16")
     gen.load_params(synthetic_params(V1, 4321, "scaled"))
     gen.set_option("tiles", tiles)
+    gen.set_option("stage", 0)  # (the whole-stage launch of round 6 has its own test below; this one is about the pair launch's tail)
     try:
         assert gen.get_option("tail") == 1
         for B, T in ((1, 1), (2, 5), (3, 37), (2, 300), (9, 260)):
@@ -303,6 +304,47 @@ def test_stage4_tail_fusion_is_bit_identical(tiles):
             assert torch.equal(tapped, plain) and torch.equal(torch.tanh(pre), plain) or float((torch.tanh(pre) - plain).abs().max()) < 1e-6
             for b, n in enumerate(frames):
                 assert not bool(fused_r[b, 256 * n :].any())
+    finally:
+        gen.close()
+
+
+@pytest.mark.parametrize("tail", [1, 0])
+def test_stage_kernel_is_bit_identical(tail):
+    """Option "stage" (round 6; default OFF — it measured slower than the launches it replaces, profiles/r06_a_stage_kernel_findings.md): the generator's whole last stage — three ResBlock1 (k = 3, 7, 11) from one LDS-resident window of ups_3's
+    output, the MRF sum in registers, mean, LeakyReLU(0.01), conv_post, tanh (model.py:112-124) — is ONE launch (kernels_bf16_stage.hip).  Same operations in
+    the same order per element as the launch-per-ResBlock path (whole-ResBlock kernels at k = 3, 7, three pair launches at k = 11, conv_post inside the last
+    or as its own kernel): the samples are BIT-IDENTICAL — one frame ... many windows (386 samples each: T = 2 already spans two), ragged batches whose
+    utterances end inside a window, micro-batches on two streams, and a tap (which takes the other path) still matches."""
+    from viettts_amd.hifigan.generator import Generator
+
+    gen = Generator(V1, device="cuda:0", dtype="bf16")
+    gen.load_params(synthetic_params(V1, 4321, "scaled"))
+    gen.set_option("tail", tail)
+    try:
+        assert gen.get_option("stage") == 0
+        for B, T in ((1, 1), (2, 2), (2, 5), (3, 37), (2, 300), (9, 260), (4, 1031)):
+            mel = torch.from_numpy(synthetic_mel(B, T, 170 + T)).to("cuda:0")
+            frames = [max(1, T - 3 * b - (T // 3) * (b % 2)) for b in range(B)]
+            gen.set_option("stage", 1)
+            fused, fused_r = gen(mel).clone(), gen.forward_ragged(mel, frames).clone()
+            tapped, pre = gen.forward_tap(mel, "pre_tanh")
+            gen.set_option("stage", 0)
+            plain, plain_r = gen(mel).clone(), gen.forward_ragged(mel, frames).clone()
+            assert torch.equal(fused, plain), (B, T, float((fused - plain).abs().max()))
+            assert torch.equal(fused_r, plain_r), (B, T, float((fused_r - plain_r).abs().max()))
+            assert torch.equal(tapped, plain)
+            for b, n in enumerate(frames):
+                assert not bool(fused_r[b, 256 * n :].any())
+        # micro-batches on two streams: every micro-batch's windows see ITS utterances' lengths and its own scratch
+        mel = torch.from_numpy(synthetic_mel(7, 90, 12)).to("cuda:0")
+        frames = [90, 3, 77, 41, 90, 1, 64]
+        gen.set_option("stage", 0)
+        want = gen.forward_ragged(mel, frames).clone()
+        gen.set_option("stage", 1)
+        for mb, streams in ((0, 1), (2, 2), (3, 1)):
+            gen.set_option("microbatch", mb)
+            gen.set_option("streams", streams)
+            assert torch.equal(gen.forward_ragged(mel, frames), want), (mb, streams)
     finally:
         gen.close()
 

@@ -19,7 +19,7 @@ CSRC = Path(__file__).resolve().parent
 ROOT = CSRC.parents[1]
 LIBDIR = CSRC.parent / "lib"
 OBJDIR = CSRC / "build"
-SOURCES = ["engine.hip", "kernels_generic.hip", "kernels_f32_mfma.hip", "kernels_f32_pair.hip", "kernels_x3.hip", "kernels_x3_rb.hip", "kernels_bf16.hip", "kernels_bf16_rbg.hip", "kernels_bf16_rbk.hip", "kernels_bf16_up.hip", "nat.hip"]
+SOURCES = ["engine.hip", "kernels_generic.hip", "kernels_f32_mfma.hip", "kernels_f32_pair.hip", "kernels_x3.hip", "kernels_x3_rb.hip", "kernels_bf16.hip", "kernels_bf16_rbg.hip", "kernels_bf16_rbk.hip", "kernels_bf16_stage.hip", "kernels_bf16_up.hip", "nat.hip"]
 HEADERS = ["vtts_internal.h", "device_common.h", "bf16_common.h", str(ROOT / "include" / "vtts_hifigan.h"), str(ROOT / "include" / "vtts_nat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # No kernel of this library may contain packed-f32 VALU instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32); hipcc's SLP vectoriser is

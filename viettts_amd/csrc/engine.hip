@@ -127,6 +127,8 @@ struct vtts_hifigan {
     int64_t opt_zigzag = 1;          // consecutive launches walk the batch in alternating directions (see next_zrev)
     unsigned zrev_count = 0;
     int64_t opt_tail = 1;            // bf16: conv_post + tanh inside the generator's last pair launch (0 = the separate streaming kernel)
+    int64_t opt_stage = 0;           // bf16: 1 = the whole last stage (three ResBlocks, MRF mean, conv_post, tanh) in ONE launch (kernels_bf16_stage.hip: bit-identical, measured
+                                     // 8.0-8.5 ms against 6.2 ms for the launches it replaces at 64 x 1024 frames: profiles/r06_a_stage_kernel_findings.md); 0 (default) = a launch per ResBlock / pair
     int64_t opt_chains = 1;          // small launches: the MRF's ResBlocks of a stage on parallel streams (0 = one after the other, 2 = always)
     hipEvent_t ev_chain[3] = {nullptr, nullptr, nullptr};  // bf16: ResBlock j's output is in the shared accumulator (orders the accumulating epilogues)
     hipStream_t side_streams[3] = {nullptr, nullptr, nullptr};
@@ -779,6 +781,51 @@ int run_resblock_bf16(vtts_hifigan* h, const Layer* rb, const void* x, int B, in
     return VTTS_OK;
 }
 
+// The generator's last stage in one launch (kernels_bf16_stage.hip): x = the stage input (ups output, raw), scratch = the stage's accumulator tensor
+// (holds the MRF sum across the third ResBlock), wav = this micro-batch's samples.  rbs[j] = first layer of ResBlock j.
+bool stage_bf16_wanted(const vtts_hifigan* h, int stage) {
+    const vtts_hifigan_cfg& c = h->cfg;
+    if (h->dtype != VTTS_BF16 || !h->opt_stage || h->opt_fuse < 2 || c.resblock == 2 || c.num_kernels != 3 || stage + 1 != c.num_upsamples) return false;
+    int ks[3], dils[3][3];
+    for (int j = 0; j < 3; ++j) {
+        const Layer* rb = &h->layers[h->idx_res[stage * 3 + j]];
+        if (!rb[0].has_rb) return false;
+        ks[j] = rb[0].k;
+        for (int z = 0; z < 3; ++z) dils[j][z] = rb[2 * z].dil;
+    }
+    const Layer& post = h->layers[h->idx_post];
+    return stage_bf16_supported(h->layers[h->idx_res[stage * 3]].cin, 3, ks, dils, post.cin, post.cout, post.k);
+}
+int run_stage_bf16(vtts_hifigan* h, int stage, const void* x, int B, int L, void* scratch, float* wav, float slope_out, hipStream_t s) {
+    BStageArgs a;
+    memset(&a, 0, sizeof(a));
+    int ks[3];
+    for (int j = 0; j < 3; ++j) {
+        const Layer* rb = &h->layers[h->idx_res[stage * 3 + j]];
+        a.wp[j] = h->blob + rb[0].off_rw;
+        a.bias[j] = reinterpret_cast<const float*>(h->blob + rb[0].off_rb);
+        ks[j] = rb[0].k;
+        for (int z = 0; z < 3; ++z) a.dils[j][z] = rb[2 * z].dil;
+    }
+    const Layer& post = h->layers[h->idx_post];
+    a.x = x;
+    a.s = scratch;
+    a.wav = wav;
+    a.post_w = reinterpret_cast<const float*>(h->blob + post.off_w);
+    a.post_b = reinterpret_cast<const float*>(h->blob + post.off_b);
+    a.B = B;
+    a.L = L;
+    a.lens = h->cur_lens ? h->cur_lens + h->cur_b0 : nullptr;
+    a.len_mul = h->cur_lens ? L / h->cur_T : 1;
+    a.zrev = next_zrev(h);
+    a.margin = stage_margin(ks, a.dils);
+    a.div = 3.0f;
+    a.slope_out = slope_out;
+    hipError_t e = launch_stage_bf16(a, s);
+    if (e != hipSuccess) return fail(VTTS_ERR_HIP, "whole-stage launch failed: %s", hipGetErrorString(e));
+    return VTTS_OK;
+}
+
 struct Taps;
 int tap_copy_bf16(const void* src, float* dst, size_t n, hipStream_t s) {
     hipError_t e = launch_bf16_to_f32(src, dst, n, s);
@@ -968,6 +1015,15 @@ int forward_bf16(vtts_hifigan* h, const float* mel, int B, int T, float* wav, vo
                 if (rc) return rc;
             }
             const float next_slope = (i + 1 < c.num_upsamples) ? 0.1f : 0.01f;  // model.py:112 / :122
+            // the whole last stage in one launch (option "stage", default OFF: it measured slower, profiles/r06_a_stage_kernel_findings.md): ups output -> three
+            // ResBlocks -> mean -> LeakyReLU -> conv_post -> tanh from one LDS-resident window per workgroup; nothing but the samples (and the MRF sum once)
+            // leaves the CU.  Not when a tap needs a tensor in between.
+            if (!tap.name && stage_bf16_wanted(h, i)) {
+                rc = run_stage_bf16(h, i, bufX, nb, (int)L, bufS, wav + (size_t)b0 * wav_len, next_slope, s);
+                if (rc) return rc;
+                tail_done = true;
+                continue;
+            }
             // the stage-4 tail (option "tail", default on): the generator's last pair launch also runs conv_post + tanh on its own rows, so the stage
             // output is never written and conv_post_bf16_k is not launched.  Where the last ResBlock ends in a pair launch that can carry it (V1: C = 32,
             // k = 11) and nothing needs the stage output itself (no tap)
@@ -1705,7 +1761,7 @@ VTTS_API int vtts_hifigan_run_pair(vtts_hifigan* h, const char* key_c1, const fl
 VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t value) {
     if (!h || !name) return fail(VTTS_ERR_INVALID, "null argument");
     {  // setting a WRITABLE option to the value it has changes nothing: captured graphs stay valid (read-only and unknown names fall through to their errors)
-        static const char* const writable[] = {"kernels", "microbatch", "fuse", "streams", "graph", "zigzag", "chains", "tiles", "tail"};
+        static const char* const writable[] = {"kernels", "microbatch", "fuse", "streams", "graph", "zigzag", "chains", "tiles", "tail", "stage"};
         for (const char* w : writable) {
             int64_t cur = 0;
             if (!strcmp(name, w) && vtts_hifigan_get_option(h, name, &cur) == VTTS_OK && cur == value) return VTTS_OK;
@@ -1739,6 +1795,9 @@ VTTS_API int vtts_hifigan_set_option(vtts_hifigan* h, const char* name, int64_t 
     } else if (!strcmp(name, "tail")) {
         if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "tail must be 0 or 1");
         h->opt_tail = value;
+    } else if (!strcmp(name, "stage")) {
+        if (value != 0 && value != 1) return fail(VTTS_ERR_INVALID, "stage must be 0 or 1");
+        h->opt_stage = value;
     } else if (!strcmp(name, "profile")) {
         h->opt_profile = value ? 1 : 0;
     } else if (!strcmp(name, "hop") || !strcmp(name, "pass_frames") || !strcmp(name, "max_frames_per_pass") || !strcmp(name, "graphs_cached") ||
@@ -1761,6 +1820,7 @@ VTTS_API int vtts_hifigan_get_option(const vtts_hifigan* h, const char* name, in
     else if (!strcmp(name, "chains")) *value = h->opt_chains;
     else if (!strcmp(name, "graph")) *value = h->opt_graph;
     else if (!strcmp(name, "tail")) *value = h->opt_tail;
+    else if (!strcmp(name, "stage")) *value = h->opt_stage;
     else if (!strcmp(name, "graphs_cached")) {
         *value = 0;
         for (auto& g : h->graphs) *value += g.exec ? 1 : 0;

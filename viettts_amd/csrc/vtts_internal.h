@@ -174,6 +174,29 @@ bool resblock_bf16_supported(int C, int K, const int* dils);
 bool resblock_bf16_preferred(int C, int K);
 hipError_t launch_resblock_bf16(int C, int K, const BConvArgs& a, hipStream_t s);
 const char* resblock_kernel_name(int C, int K);
+// the generator's whole LAST stage — three ResBlock1 of C = 32 from one LDS-resident window, the MRF mean, LeakyReLU(0.01), conv_post, tanh — in one
+// launch (kernels_bf16_stage.hip), bit-identical to the launch-per-ResBlock path
+struct BStageArgs {
+    const void* x;            // stage input (ups_3's output), raw bf16 [B][L][32]
+    const void* wp[3];        // per ResBlock: its six convolutions' A fragments (Layer::off_rw: pair_g_pack_geom order, contiguous)
+    const float* bias[3];     // per ResBlock: 6 x [32] fp32 (Layer::off_rb)
+    int dils[3][3];           // per ResBlock: the three pairs' rates
+    void* s;                  // scratch bf16 [B][L][32]: the MRF sum across the third ResBlock (only the rows a window reads back are written)
+    float* wav;               // [B][L] fp32
+    const float* post_w;      // conv_post's plain fp32 weights [7][32] (Haiku [K][Cin][1]) and bias
+    const float* post_b;
+    int B, L;                 // utterances; rows allocated per utterance
+    const int* lens;          // ragged batch (as BConvArgs)
+    int len_mul;
+    int zrev;
+    int margin;               // stage_margin(): rows per window side whose dependency cone leaves the window (+ conv_post's 3)
+    float div, slope_out;     // MRF divisor (num_kernels), the tail's LeakyReLU slope (model.py:121-122)
+    unsigned long long* dbg;  // kernel-development builds only (-DVTTS_TIMELINE=1, VTTS_ST_TL=<file>): per-workgroup s_memtime stamps; nullptr otherwise
+};
+bool stage_bf16_supported(int C, int nk, const int* ks, const int (*dils)[3], int post_cin, int post_cout, int post_k);
+int stage_margin(const int* ks, const int (*dils)[3]);
+hipError_t launch_stage_bf16(const BStageArgs& a, hipStream_t s);
+const char* stage_kernel_name();
 // the four transposed convolutions on the register-streamed structure (kernels_bf16_up.hip): cls = BCLS_UP0..3,
 // a.wp = the 3-tap polyphase form's weights packed with convt_g_pack_geom(cls) (bf16_pack)
 hipError_t launch_convt_g_bf16(int cls, const BConvArgs& a, hipStream_t s);
