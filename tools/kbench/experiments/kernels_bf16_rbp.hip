@@ -33,7 +33,8 @@
 
 #include "bf16_common.h"
 
-#ifndef PEXP  // kernel-development switches (tools/kbench): bit 0 = no fillers, bit 1 = no DMA / residual bursts, bit 2 = B reads late in the step (first cut), bit 3 = no epilogue-2 stores, bit 4 = c2 accumulators not pinned to AGPRs
+#ifndef PEXP  // kernel-development switches (tools/kbench): bit 0 = no fillers, bit 1 = no DMA / residual bursts, bit 2 = B reads late in the step (first cut), bit 3 = no epilogue-2 stores, bit 4 = c2 accumulators not pinned to AGPRs,
+              // bit 5 (round 6) = EXPLICIT issue order: every MFMA followed by its memory instruction and a 1-4 instruction slice of a filler unit, fenced by sched_barrier(0)
 #define PEXP 0
 #endif
 
@@ -80,7 +81,7 @@ struct PTile {
     static_assert(THREADS == 256, "one wave per SIMD");
     static_assert(C % (WM * 32) == 0 && N1 % (WN * 32) == 0, "tile/wave mismatch");
     static_assert(KSTEPS == UB, "a block is one tap (C = 128)");
-    static_assert(RA == 4 && UB % RA == 0, "ring slot of a step is its position in the block");
+    static_assert((RA == 4 || RA == 8) && UB % RA == 0, "ring slot of a step is its position in the block");
     static_assert(NBE <= NBLK - 1 && NBL <= NBLK - 1, "the last block of each loop carries the burst");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     static_assert(SPR == 16, "swizzle / DMA lane map written for 256-byte rows");
@@ -280,6 +281,68 @@ __global__ __launch_bounds__(T::THREADS, 1) void resblock_pair_p_bf16_k(BConvArg
         else __builtin_amdgcn_raw_buffer_store_b128(o, rs, off, (r.t0 + nr * 32) * P, 0);
     };
 
+    // ---------------- round 6 (PEXP bit 5): the filler units cut into slices of <= 4 instructions, one per MFMA slot ------------------------------
+    unsigned eq[4], epk[4];
+    float ev[8];
+    auto ep2_slice = [&](const PTileRef& r, auto u_tag, auto s_tag) {
+        constexpr int u = decltype(u_tag)::value, S = decltype(s_tag)::value;
+        constexpr int nr = u % NR, p = (u / NR) % 2, mr = u / (2 * NR), r0 = 8 * p;
+        if constexpr (S == 0) {
+            eq[0] = rv[u].x; eq[1] = rv[u].y; eq[2] = rv[u].z; eq[3] = rv[u].w;
+            swap_pair(eq[0], eq[2]);
+        } else if constexpr (S == 1) {
+            swap_pair(eq[1], eq[3]);
+        } else if constexpr (S >= 2 && S < 10) {
+            asm("v_accvgpr_read_b32 %0, %1" : "=v"(ev[S - 2]) : "a"(accB[mr][nr][r0 + S - 2]));
+        } else if constexpr (S >= 10 && S < 18) {
+            constexpr int e = S - 10;
+            ev[e] = ((e & 1) ? bf16_hi(eq[e / 2]) : bf16_lo(eq[e / 2])) + ev[e];
+        } else if constexpr (S >= 18 && S < 22) {
+            epk[S - 18] = pack_bf16x2(ev[2 * (S - 18)], ev[2 * (S - 18) + 1]);
+        } else if constexpr (S == 22) {
+            swap_pair(epk[0], epk[2]);
+        } else if constexpr (S == 23) {
+            swap_pair(epk[1], epk[3]);
+        } else if constexpr (S == 24) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(ybase + (size_t)r.b * Lp * C, 0, r.L * P, 0x00020000);
+            unsigned off = e_voff + (mr * 32 + p * 16) * 2;
+            if constexpr ((WN - 1) * (N1 / WN) + nr * 32 + 31 >= NT2) off = (wn * (N1 / WN) + nr * 32 + l31 < NT2) ? off : DROP;
+            const u32x4 o = {epk[0], epk[1], epk[2], epk[3]};
+            if constexpr (PEXP & 8) asm volatile("" ::"v"(o));
+            else __builtin_amdgcn_raw_buffer_store_b128(o, rs, off, (r.t0 + nr * 32) * P, 0);
+        }
+    };
+    uint4 lv;
+    float la[2];
+    auto lrelu_slice = [&](unsigned addr, auto s_tag, auto edge_tag, const PTileRef& rn, int j) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        if constexpr (S == 0) {
+            lv = *reinterpret_cast<const uint4*>(lds + addr);
+        } else if constexpr (S == 7) {
+            if constexpr (EDGE) {
+                const int row = RPD * (wave + NWAVES * j) + lane / SPR;
+                const bool ok = (unsigned)(rn.t0 - H2 - H1 + row) < (unsigned)rn.L;
+                lv.x = ok ? lv.x : 0u; lv.y = ok ? lv.y : 0u; lv.z = ok ? lv.z : 0u; lv.w = ok ? lv.w : 0u;
+            }
+        } else if constexpr (S >= 8 && S < 24) {
+            constexpr int c = (S - 8) / 4, st = (S - 8) % 4;
+            unsigned& w = c == 0 ? lv.x : (c == 1 ? lv.y : (c == 2 ? lv.z : lv.w));
+            if constexpr (st == 0) {
+                la[0] = bf16_lo(w);
+                la[1] = bf16_hi(w);
+            } else if constexpr (st == 1) {
+                la[0] = vmax_raw(la[0], vmul_raw(la[0], 0.1f));
+            } else if constexpr (st == 2) {
+                la[1] = vmax_raw(la[1], vmul_raw(la[1], 0.1f));
+            } else {
+                w = pack_bf16x2(la[0], la[1]);
+            }
+        } else if constexpr (S == 24) {
+            *reinterpret_cast<uint4*>(lds + addr) = lv;
+        }
+    };
+
     // ---------------- one block of UB k-steps (= one tap) of the MFMA stream, with its fillers ------------------------------
     // PHASE 0: c1 over X (taps at rate DIL), accumulators accA;  PHASE 1: c2 over xt (rate 1), accumulators accB.
     // SIDE: 0 none | 1 QE epilogue-2 units starting at EU0 | 2 QL in-place LeakyReLU units from unit j0 (interior tile) |
@@ -301,6 +364,47 @@ __global__ __launch_bounds__(T::THREADS, 1) void resblock_pair_p_bf16_k(BConvArg
             opaque(laddr);
             laddr += nbuf_off + (unsigned)j0 * (NWAVES * 1024);
         }
+        if constexpr (PEXP & 32) {
+            // ---- round 6: the issue order written out.  Slot (i, k) = behind MFMA k of k-step i: the memory instruction due there (k < NR: the next step's B
+            // fragment of column block k; k < NR + MR: the A fragment PA steps ahead) and one SLICE of a filler unit (<= 4 instructions whose operands were
+            // produced at least 6 slots earlier), then a scheduling barrier: hipcc neither clumps the fillers in front of the step nor sinks a load to its use.
+            static_for<UB>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                static_for<MR * NR>([&](auto k_tag) {
+                    constexpr int k = decltype(k_tag)::value, mr = k / NR, nr = k % NR, slot = i * (MR * NR) + k;
+                    if constexpr (PHASE == 0)
+                        accA[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % RA][mr], bfr[i & 1][nr], (FIRST && i == 0) ? bblk[mr] : accA[mr][nr], 0, 0, 0);
+                    else
+                        accB[mr][nr] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i % RA][mr], bfr[i & 1][nr], (FIRST && i == 0) ? bblk[mr] : accB[mr][nr], 0, 0, 0);
+                    if constexpr (k < NR) {
+                        if constexpr (i + 1 < UB) bfr[(i + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(lds + tapaddr + (xs ^ (unsigned)((i + 1) << 5)) + k * 32 * P);
+                        else if constexpr (!LAST) bfr[(i + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(lds + tapaddr_n + xs_n + k * 32 * P);
+                    } else if constexpr (k < NR + MR) {
+                        int ga = g0 + i + PA;
+                        ga = ga >= 2 * NQ ? ga - 2 * NQ : ga;
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, a_voff + (k - NR) * 1024, ga * (MB * 1024), 0);
+                        af[(i + PA) % RA][k - NR] = __builtin_bit_cast(bf16x8, v);
+                    }
+                    if constexpr (PEXP & 1) {
+                    } else if constexpr (SIDE == 1) {
+                        constexpr int U = EU0 + slot / 32, S = slot % 32;
+                        if constexpr (U < NE2) ep2_slice(rprev, std::integral_constant<int, U>{}, std::integral_constant<int, S>{});
+                    } else if constexpr (SIDE == 2 || SIDE == 5) {
+                        constexpr int q = slot / 32, S = slot % 32;
+                        if constexpr (q < QL) lrelu_slice(laddr + q * (NWAVES * 1024), std::integral_constant<int, S>{}, std::integral_constant<bool, SIDE == 5>{}, rnext, j0 + q);
+                    } else if constexpr (SIDE == 3) {
+                        constexpr int per = (NDW + UB - 1) / UB;
+                        if constexpr (k >= MR * NR - per) {
+                            constexpr int j = i * per + (k - (MR * NR - per));
+                            if constexpr (j < NDW && !(PEXP & 2)) dma_interior(rnext, nbuf_off, j);
+                        }
+                    } else if constexpr (SIDE == 4) {
+                        if constexpr (i == UB - 1 && k == MR * NR - 1 && !(PEXP & 2)) resid_issue(rcur);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        } else {
         static_for<UB>([&](auto i_tag) {
             constexpr int i = decltype(i_tag)::value;
             int ga = g0 + i + PA;
@@ -358,6 +462,7 @@ __global__ __launch_bounds__(T::THREADS, 1) void resblock_pair_p_bf16_k(BConvArg
                 }
             }
         });
+        }
         // keep the c2 accumulators in the accumulator half of the register file across blocks (hipcc moved them into arch
         // VGPRs for the c2 loop: 256 moves per tile, and MFMAs whose C/D share the A/B operands' register banks)
         if constexpr (PHASE == 1 && !(PEXP & 16)) {
@@ -534,7 +639,10 @@ __global__ __launch_bounds__(T::THREADS, 1) void resblock_pair_p_bf16_k(BConvArg
 // ---- tile table -------------------------------------------------------------------------------------
 //                                                     C   KS  DIL  N1  WM WN PA QE QL
 template <int KS, int DIL> struct P128;
-template <int DIL> struct P128<11, DIL> { using type = PTile<128, 11, DIL, 256, 2, 2, 3, 2, 2>; };
+#ifndef PEXP_PA  // round 6: A-fragment look-ahead in k-steps (3 = a 4-slot ring; 7 = an 8-slot ring: stores and slow loads issued behind a fragment request do not delay it)
+#define PEXP_PA 3
+#endif
+template <int DIL> struct P128<11, DIL> { using type = PTile<128, 11, DIL, 256, 2, 2, PEXP_PA, 2, 2>; };
 template <int DIL> struct P128<7, DIL> { using type = PTile<128, 7, DIL, 256, 2, 2, 3, 4, 4>; };
 
 static int g_num_cus = 0;
