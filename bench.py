@@ -270,6 +270,8 @@ def pipeline_256(n=256, gen=None, rank=0, world=1, barrier=None, passes=3, nat_b
     am = vdist.setup_model_dp(AcousticModel(device=str(gen.device)), lambda m: m.load_params(*synthetic_acoustic_checkpoint()))
     if nat_bf16x3:  # the acoustic model's split-precision option (include/vtts_nat.h): for a bf16-class vocoder the mel's 1e-5 is noise
         am.set_option("bf16x3", 1)
+    if os.environ.get("VTTS_NAT_PP_SPLIT"):  # development A/B against an experiment build (VTTS_NAT_PP_EXP, tools/r06_nat_ab.sh): the decoder's projection + prenet step cut along its weights
+        am.set_option("pp_split", int(os.environ["VTTS_NAT_PP_SPLIT"]))
     tdir = os.path.join(REPO, "tests", "golden", "text")
     sents = transcript_sentences(n, os.path.join(tdir, "transcript.txt"), os.path.join(tdir, "lexicon.txt"))
     out = {}

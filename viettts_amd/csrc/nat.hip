@@ -248,6 +248,7 @@ static inline float nat_bf16_to_float(unsigned short h) {
 struct vtts_nat_acoustic : NatModel {
     vtts_nat_acoustic_cfg cfg;
     int x3 = 0;  // option "bf16x3": LSTM steps, gate GEMM and postnet as three bf16 x bf16 terms per product on the bf16 matrix pipe
+    int pp_split = 0;  // experiment builds (VTTS_NAT_PP_EXP) only: 1 = the decoder's projection + prenet step cut along its weights (measured slower; see nat_dec_proj_prenet_k)
     // forward_groups(): the postnet of a group of rows runs on `side` as soon as the decoder has produced the group's last frame
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gates = nullptr;
@@ -1422,6 +1423,12 @@ __global__ __launch_bounds__(1024) void nat_dec_proj_prenet_k(const float* __res
     }
 }
 
+// (Round 6 cut the projection + prenet step along its WEIGHTS — a workgroup = a 32-sentence tile x a slice of a matrix, two launches per frame over 64-workgroup
+//  grids, every load requested before the first wait — and measured it SLOWER: 6.7 + 24.0 us per frame against this kernel's 15.2, the acoustic model 17.0 ms against
+//  12.5 (profiles/r06_c_nat_proj_prenet_findings.md).  The kernels live in tools/kbench/experiments/nat_pp_split_*.inc: --define VTTS_NAT_PP_EXP=1, option "pp_split".)
+#ifdef VTTS_NAT_PP_EXP
+#include "../../tools/kbench/experiments/nat_pp_split_kernels.inc"
+#endif
 // ---- shared host-side sequence: TokenEncoder of `m` under module prefix `te` -> enc [B][Lmax][2D] ------------------
 // scratch of the two encoder LSTMs: XT[2][Lmax], HS[2][Lmax + 1] slabs of [D][Bp] and the two cell states
 size_t nat_enc_lstm_floats(int D, int B, int Lmax) {
@@ -1730,6 +1737,13 @@ VTTS_API int vtts_nat_acoustic_set_option(vtts_nat_acoustic* h, const char* key,
         h->x3 = value;
         return VTTS_OK;
     }
+#ifdef VTTS_NAT_PP_EXP
+    if (!strcmp(key, "pp_split")) {
+        if (value != 0 && value != 1) return failf(VTTS_ERR_INVALID, "pp_split must be 0 or 1 (got %d)", value);
+        h->pp_split = value;
+        return VTTS_OK;
+    }
+#endif
     return failf(VTTS_ERR_INVALID, "unknown option '%s' (known: bf16x3)", key);
 }
 VTTS_API int vtts_nat_acoustic_get_option(const vtts_nat_acoustic* h, const char* key, int* value) {
@@ -1738,6 +1752,12 @@ VTTS_API int vtts_nat_acoustic_get_option(const vtts_nat_acoustic* h, const char
         *value = h->x3;
         return VTTS_OK;
     }
+#ifdef VTTS_NAT_PP_EXP
+    if (!strcmp(key, "pp_split")) {
+        *value = h->pp_split;
+        return VTTS_OK;
+    }
+#endif
     return failf(VTTS_ERR_INVALID, "unknown option '%s' (known: bf16x3)", key);
 }
 VTTS_API int vtts_nat_acoustic_num_params(const vtts_nat_acoustic* h, int* n) {
@@ -1781,6 +1801,9 @@ VTTS_API int vtts_nat_acoustic_workspace_bytes(const vtts_nat_acoustic* h, int B
              + align_up(nat_dec_state_floats(h->cfg, B) * 4, 256)                                          // decoder state Z[2], c1, c2
              + 2 * align_up((size_t)B * Fmax * 4 * h->cfg.decoder_dim * 4, 256)                           // hoisted gate pre-activations G1, G2
              + align_up(nat_enc_lstm_floats((int)D, B, Lmax) * 4, 256)                                     // encoder LSTMs' scratch
+#ifdef VTTS_NAT_PP_EXP
+             + align_up(nat_pp_part_floats((int)MEL, B) * 4, 256)                                          // the projection's partial sums of a frame
+#endif
              + 4096;                                                                                       // resident decoder kernel: barrier counters, failure flag
     return VTTS_OK;
 }
@@ -1873,6 +1896,9 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
     float* G1 = take((size_t)B * Fmax * G4 * 4);
     float* G2 = take((size_t)B * Fmax * G4 * 4);
     float* lstm_ws = take(nat_enc_lstm_floats(D, B, Lmax) * 4);
+#ifdef VTTS_NAT_PP_EXP
+    float4* ppart = reinterpret_cast<float4*>(take(nat_pp_part_floats(MEL, B) * 4));
+#endif
     unsigned* ctl = reinterpret_cast<unsigned*>(take(4096));
     if (enc_pre) {
         enc = const_cast<float*>(enc_pre);  // read only from here on
@@ -1963,6 +1989,12 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
             else hipLaunchKernelGGL((nat_dec_lstm_k<1, 8>), lgrid, dim3(512), 0, s, o, o, KA, H, nframes_dev, f, B, Bp, H);
         };
         const size_t plds = ((size_t)2 * H + 1024 + MEL + PN) * sizeof(float4);
+#ifdef VTTS_NAT_PP_EXP  // the projection + prenet step cut along its weights (round 6 experiment; option "pp_split")
+        const bool pp_split = h->pp_split && nat_pp_split_ok(PN, H, MEL);
+        const dim3 pgridA(NAT_PP_NSL, (B + NAT_PP_TS - 1) / NAT_PP_TS), pgridB(PN / 32, (B + NAT_PP_TS - 1) / NAT_PP_TS);
+        const int pthreadsA = 640;
+        const size_t pldsA = (size_t)128 * 8 * sizeof(float4), pldsB = ((size_t)80 * 8 + (size_t)256 * 8 + 2 * 8 * 32) * sizeof(float4);
+#endif
         auto group_handover = [&](int frames_done) -> int {  // a group whose last frame was frames_done - 1: its postnet starts now, on the side stream
             for (int g = 0; g < ngroups; ++g) {
                 if (group_frames[g] != frames_done) continue;
@@ -1997,16 +2029,30 @@ static int nat_acoustic_run(vtts_nat_acoustic* h, const int32_t* tokens_dev, con
                 const unsigned short* zpx = reinterpret_cast<const unsigned short*>(zp);
                 lstm_x3(zcx, zpx, PN, PN + H, w1x, G1, c1, PN, f);
                 lstm_x3(zcx, zpx, PN + H, PN + 2 * H, w2x, G2, c2, PN + H, f);
-                hipLaunchKernelGGL(nat_dec_proj_prenet_k<true>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f,
-                                   B, Bp, Fmax, PN, H, MEL, zplane);
+#ifdef VTTS_NAT_PP_EXP
+                if (pp_split) {
+                    hipLaunchKernelGGL(nat_dec_proj_part_k<true>, pgridA, dim3(pthreadsA), pldsA, s, zc, nframes_dev, wp, ppart, f, B, Bp, PN, H, MEL, zplane);
+                    hipLaunchKernelGGL(nat_dec_prenet_k<true>, pgridB, dim3(512), pldsB, s, zp, nframes_dev, f1, f2, ppart, bp, keep_dev, mel0, f, B, Bp, Fmax, PN, MEL,
+                                       zplane);
+                } else
+#endif
+                    hipLaunchKernelGGL(nat_dec_proj_prenet_k<true>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f,
+                                       B, Bp, Fmax, PN, H, MEL, zplane);
                 rc = group_handover(f + 1);
                 if (rc) return rc;
                 continue;
             }
             lstm(zc, PN, zp + (size_t)PN * Bp, w1, G1, c1, zc + (size_t)PN * Bp, f);
             lstm(zc, PN + H, zp + (size_t)(PN + H) * Bp, w2, G2, c2, zc + (size_t)(PN + H) * Bp, f);
-            hipLaunchKernelGGL(nat_dec_proj_prenet_k<false>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f, B,
-                               Bp, Fmax, PN, H, MEL, (size_t)0);
+#ifdef VTTS_NAT_PP_EXP
+            if (pp_split) {
+                hipLaunchKernelGGL(nat_dec_proj_part_k<false>, pgridA, dim3(pthreadsA), pldsA, s, zc, nframes_dev, wp, ppart, f, B, Bp, PN, H, MEL, (size_t)0);
+                hipLaunchKernelGGL(nat_dec_prenet_k<false>, pgridB, dim3(512), pldsB, s, zp, nframes_dev, f1, f2, ppart, bp, keep_dev, mel0, f, B, Bp, Fmax, PN, MEL,
+                                   (size_t)0);
+            } else
+#endif
+                hipLaunchKernelGGL(nat_dec_proj_prenet_k<false>, dim3((B + 3) / 4), dim3(1024), plds, s, zc, zp, nframes_dev, f1, f2, wp, bp, keep_dev, mel0, f, B,
+                                   Bp, Fmax, PN, H, MEL, (size_t)0);
             rc = group_handover(f + 1);  // under the remaining decoder steps
             if (rc) return rc;
         }
