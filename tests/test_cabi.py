@@ -165,3 +165,21 @@ def test_built_library_has_no_packed_f32_valu():
     counts = count_packed_f32(Path(_lib.default_lib_path()))
     assert len(counts) == len(build.SOURCES) and sum(m for _, m in counts.values()) > 5000  # every translation unit's code object was found and disassembled
     assert all(pk == 0 for pk, _ in counts.values()), counts
+
+
+def test_experiment_includes_still_compile(tmp_path):
+    """Development-only code lives OUT of the product sources (round 6: `tools/kbench/experiments/nat_*.inc`, included by `nat.hip` only under
+    `-DVTTS_NAT_PERSIST` / `-DVTTS_NAT_PKFMA` / `-DVTTS_NAT_PP_EXP`; the timeline stamps of the stage / whole-ResBlock kernels under `-DVTTS_TIMELINE`).
+    The findings under profiles/ cite those builds as provenance, so they must not rot: the three files that carry them compile with every switch on."""
+    import subprocess
+
+    from viettts_amd.csrc import build
+
+    defs = ["-DVTTS_NAT_PERSIST=1", "-DVTTS_NAT_PKFMA=7", "-DVTTS_NAT_PP_EXP=1", "-DVTTS_TIMELINE=1"]
+    procs = []
+    for src in ("nat.hip", "kernels_bf16_stage.hip", "kernels_x3_rb.hip"):
+        cmd = [build._hipcc(), *build.FLAGS, *build.FILE_FLAGS[src], *defs, "-c", str(build.CSRC / src), "-o", str(tmp_path / (src + ".o"))]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for src, p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0, (src, err[-2000:])
