@@ -440,6 +440,9 @@ hipError_t launch_pair_x3(const ConvArgs& a, const void* w1, const void* w2, con
 // a lane ends up with consecutive output samples of one channel: SH = 4 -> a float4 per group (16 contiguous bytes of y[co][8 q + 4 g ..]),
 // SH = 1 -> a float2 of both groups (y[co][2 q], y[co][2 q + 1]).  fp32 in HBM on both sides, as everything outside the matrix products.
 // =====================================================================================================
+#ifndef VTTS_UX_STAGED
+#define VTTS_UX_STAGED 1
+#endif
 template <int CIN_, int COUT_, int SH_, int N1_, int WM_, int WN_>
 struct UXTile {
     static constexpr int CIN = CIN_, COUT = COUT_, SH = SH_, S = 2 * SH_, N1 = N1_, WM = WM_, WN = WN_;
@@ -452,6 +455,9 @@ struct UXTile {
     static constexpr int PLANE = tile_rows16(ROWS) * P;
     static constexpr int LDS_BYTES = 2 * PLANE;
     static constexpr size_t PLANE_W = (size_t)4 * KSTEPS * MB * 1024;  // bytes of one weight plane: [g][m][ks][mblk][lane][8]
+    // SH = 1: the output rows leave through an fp32 transposition area in the planes' LDS (kernel-development switch VTTS_UX_STAGED, default on)
+    static constexpr int FS = 2 * N1 + 4;
+    static constexpr bool STAGED = VTTS_UX_STAGED && SH == 1 && (size_t)MT * FS * 4 <= (size_t)LDS_BYTES;
     static_assert(MPG % MT == 0 && N1 % (WN * 32) == 0 && (SH == 4 || SH == 1) && KSTEPS % 2 == 0, "tiling");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
@@ -602,13 +608,42 @@ __global__ __launch_bounds__(T::THREADS, 2) void convt_x3_k(ConvArgs a) {
                     const float4 o = make_float4(acc[g][nr][4 * rq + 0] + bv, acc[g][nr][4 * rq + 1] + bv, acc[g][nr][4 * rq + 2] + bv, acc[g][nr][4 * rq + 3] + bv);
                     *reinterpret_cast<float4*>(yb + (long)co * Lout + (long)S * q + 4 * g) = o;
                 }
-        } else {
+        } else if constexpr (!T::STAGED) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = mblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float bv = a.bias[co];
                 *reinterpret_cast<float2*>(yb + (long)co * Lout + 2l * q) = make_float2(acc[0][nr][r] + bv, acc[1][nr][r] + bv);
             }
+        }
+    }
+    if constexpr (SH == 1 && T::STAGED) {
+        // Round 6: the stride-2 upsamplers are HBM-bound (3.6-3.9 TB/s) and stored 8 bytes per lane, 32 lanes = 256 bytes per channel row and instruction.
+        // The output rows go through an fp32 area [MT][2 N1 + 4] in the (dead) planes' LDS and leave as 16-byte units, a wave = 1 KiB of one row — the bf16
+        // engine's UTile epilogue (kernels_bf16_up.hip).  Same sums, same bias addition: the same bits.
+        constexpr int FS = T::FS;
+        float* const fs = reinterpret_cast<float*>(lds);
+        __syncthreads();  // every wave is done reading the tiles
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const int ql = wn * (N1 / WN) + nr * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float bv = a.bias[blockIdx.y * T::MT + col];
+                *reinterpret_cast<float2*>(fs + col * FS + 2 * ql) = make_float2(acc[0][nr][r] + bv, acc[1][nr][r] + bv);
+            }
+        }
+        __syncthreads();
+        constexpr int UPR = N1 / 2;  // 16-byte units per output row of the tile (2 N1 samples)
+        const long s0 = 2l * t0, send = 2l * L;
+        for (int u = tid; u < T::MT * UPR; u += T::THREADS) {
+            const int col = u / UPR, x4 = u - col * UPR;
+            const long sidx = s0 + 4l * x4;
+            float* dst = yb + (long)(blockIdx.y * T::MT + col) * Lout + sidx;
+            const float4 v = *reinterpret_cast<const float4*>(fs + col * FS + 4 * x4);
+            if (sidx + 3 < send) *reinterpret_cast<float4*>(dst) = v;
+            else if (sidx + 1 < send) *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.y);
         }
     }
 }
