@@ -1,5 +1,5 @@
 #!/bin/bash
-# NAT decoder development: tests, a short A/B of option "pp_split", and the decoder kernels' per-launch durations (rocprofv3) with the option on
+# NAT decoder development (needs an experiment build: python -m viettts_amd.csrc.build --define VTTS_NAT_PP_EXP=1 --libname libvtts_ppexp.so, then VTTS_HIFIGAN_LIB=...): tests, a short A/B of option "pp_split", and the decoder kernels' per-launch durations (rocprofv3) with the option on
 T=${1:-r06_nat}; R=$PWD; O=$R/gpurun_out/$T; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_nat.py -m gpu -q -x --timeout 600 2>&1 | tail -3
 for rep in 1 2; do for pp in 1 0; do
