@@ -1,6 +1,9 @@
 #!/bin/bash
-# NAT decoder: nat_dec_proj_prenet_k with its idle wave warming the prenet matrices into L2 (default) against without (libvtts_nowarm.so = --define VTTS_NAT_PP_WARM=0):
-# tests, interleaved per-stage pipeline times, per-launch durations
+# NAT decoder (round 6 experiment, NOT in the tree any more: neutral-to-worse, profiles/r06_c_nat_warm_ab.txt): nat_dec_proj_prenet_k with its idle wave touching every line of
+# the prenet matrices at the kernel's start (libvtts_hifigan.so of that build) against without (libvtts_nowarm.so = --define VTTS_NAT_PP_WARM=0): tests, interleaved per-stage
+# pipeline times, per-launch durations
+
+
 T=${1:-r06_warm}; R=$PWD; O=$R/gpurun_out/$T; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_nat.py -m gpu -q -x --timeout 600 -k "acoustic or text2mel" 2>&1 | tail -2
 for rep in 1 2 3; do for v in libvtts_hifigan.so libvtts_nowarm.so; do for mode in x3 fp32; do
